@@ -1,0 +1,14 @@
+"""MI355X-native bootstrap particle filter behind DiscretePOMP.jl's model plugin surface.
+
+The directory name carries a dot (``discretepomp.jl_amd``), which Python cannot import by
+name; import it through the repo-root shim ``dpomp_amd`` (``import dpomp_amd``).
+"""
+from ._abi import (DpompLibraryMissing, ST_EVENT_CAP, ST_ZERO_WEIGHT, RS_SYSTEMATIC, RS_STRATIFIED,
+                   RS_MULTINOMIAL, DBG_LOGW, DBG_OFFSPRING_END, load_library)
+from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, RateFunction, RateTerm,
+                    UniformProductPrior, dmy_obs_fn, generate_custom_model, generate_model,
+                    generate_weak_prior, get_observations, partial_gaussian_obs_model)
+from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population,
+                              get_particle_filter_lpdf)
+
+__all__ = [n for n in dir() if not n.startswith("_")]

@@ -1,0 +1,130 @@
+"""ctypes view of include/dpomp.h and the loader of the HIP library.
+
+There is deliberately no CPU implementation behind this module: if
+``libdpomp_hip.so`` is missing the import of the filter fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdpomp_hip.so")
+
+ABI_VERSION = 1
+MAX_STATES = 8
+MAX_EVENTS = 8
+MAX_PARAMS = 8
+MAX_FACTORS = 2
+
+OK = 0
+EINVAL, EDEVICE, ENOMEM, ESTATE = -1, -2, -3, -4
+ST_EVENT_CAP = 1
+ST_ZERO_WEIGHT = 2
+RATE_LEFT, RATE_RATIO = 0, 1
+OBS_GAUSSIAN = 1
+RS_SYSTEMATIC, RS_STRATIFIED, RS_MULTINOMIAL = 1, 2, 3
+(BUILTIN_GENERIC, BUILTIN_SI, BUILTIN_SIR, BUILTIN_SEI, BUILTIN_SEIR, BUILTIN_SI_FD, BUILTIN_SIR_FD,
+ BUILTIN_SEI_FD, BUILTIN_SEIR_FD, BUILTIN_LOTKA, BUILTIN_ROSSMAC) = range(11)
+DBG_LOGW, DBG_OFFSPRING_END = 1, 2
+
+
+class RateTermC(C.Structure):
+    _fields_ = [
+        ("theta_index", C.c_int32),
+        ("form", C.c_int32),
+        ("n_factors", C.c_int32),
+        ("factor_mask", C.c_uint32 * MAX_FACTORS),
+        ("denom_mask", C.c_uint32),
+    ]
+
+
+class ObsModelC(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("state_mask", C.c_uint32),
+        ("value_mask", C.c_uint32),
+        ("reserved", C.c_int32),
+        ("sigma", C.c_double),
+    ]
+
+
+class ModelDescC(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_states", C.c_int32),
+        ("n_events", C.c_int32),
+        ("n_params", C.c_int32),
+        ("builtin_id", C.c_int32),
+        ("t0_index", C.c_int32),
+        ("initial_condition", C.c_int64 * MAX_STATES),
+        ("transition", (C.c_int32 * MAX_STATES) * MAX_EVENTS),
+        ("rate", RateTermC * MAX_EVENTS),
+        ("obs", ObsModelC),
+        ("n_obs", C.c_int32),
+        ("n_obs_values", C.c_int32),
+        ("obs_time", C.POINTER(C.c_double)),
+        ("obs_id", C.POINTER(C.c_int64)),
+        ("obs_value", C.POINTER(C.c_int64)),
+        ("max_events_per_interval", C.c_int64),
+    ]
+
+
+_PROTOTYPES = {
+    "dpomp_device_count": (C.c_int, []),
+    "dpomp_version": (C.c_char_p, []),
+    "dpomp_last_global_error": (C.c_char_p, []),
+    "dpomp_create": (C.c_int, [C.POINTER(ModelDescC), C.c_int, C.POINTER(C.c_void_p)]),
+    "dpomp_destroy": (None, [C.c_void_p]),
+    "dpomp_last_error": (C.c_char_p, [C.c_void_p]),
+    "dpomp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dpomp_set_resampler": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpomp_pf_loglik": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
+                                  C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "dpomp_pop_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "dpomp_pop_free": (None, [C.c_void_p, C.c_void_p]),
+    "dpomp_pf_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,
+                                   C.c_uint64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "dpomp_pop_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "dpomp_pop_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "dpomp_pop_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "dpomp_simulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
+                                 C.c_int64, C.POINTER(C.c_int64)]),
+    "dpomp_debug_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "dpomp_selftest_numerics": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dpomp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpomp_kernel_count": (C.c_int, []),
+    "dpomp_kernel_name": (C.c_char_p, [C.c_int]),
+    "dpomp_get_kernel_stat": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "dpomp_last_event_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+class DpompLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library() -> C.CDLL:
+    """Load libdpomp_hip.so (built by ``__graft_entry__.build()`` / ``build.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DpompLibraryMissing(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the particle filter.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_PROTOTYPES)

@@ -1,0 +1,660 @@
+// dpomp_api.hip -- the C ABI of include/dpomp.h and the host-side step sequencer
+// (partial_log_likelihood!, src/hmm_particle_filter.jl:39-76, as a stream of kernel launches
+// over a device-resident population; no host synchronisation inside a call).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dpomp.h"
+#include "dpomp_kernels.h"
+
+using namespace dpomp;
+
+namespace {
+
+thread_local std::string g_global_error;
+
+enum KernelId { KID_INIT = 0, KID_PROPAGATE, KID_WSUM, KID_SCAN_BLOCKS, KID_OFFSETS, KID_GATHER, KID_COPYSEG, KID_COUNT };
+const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum",         "k_scan_blocks",
+                                             "k_offsets", "k_gather",    "k_copy_segments"};
+
+typedef void (*PropFn)(PropArgs);
+
+struct PropEntry {
+    int builtin, S, E;
+    PropFn fn;
+};
+
+// (rate evaluator, S, E) instances compiled for the catalogue of generate_model
+// (src/hmm_examples.jl:171-204); anything else runs the table-driven RGeneric.
+const PropEntry kPropTable[] = {
+    {DPOMP_BUILTIN_SI, 2, 1, k_propagate<RSi<false>>},
+    {DPOMP_BUILTIN_SI_FD, 2, 1, k_propagate<RSi<true>>},
+    {DPOMP_BUILTIN_SIR, 3, 2, k_propagate<RSir<3, false>>},
+    {DPOMP_BUILTIN_SIR, 2, 2, k_propagate<RSir<2, false>>},
+    {DPOMP_BUILTIN_SIR_FD, 3, 2, k_propagate<RSir<3, true>>},
+    {DPOMP_BUILTIN_SIR_FD, 2, 2, k_propagate<RSir<2, true>>},
+    {DPOMP_BUILTIN_SEI, 3, 2, k_propagate<RSei<false>>},
+    {DPOMP_BUILTIN_SEI_FD, 3, 2, k_propagate<RSei<true>>},
+    {DPOMP_BUILTIN_SEIR, 4, 3, k_propagate<RSeir<4, false>>},
+    {DPOMP_BUILTIN_SEIR, 3, 3, k_propagate<RSeir<3, false>>},
+    {DPOMP_BUILTIN_SEIR_FD, 4, 3, k_propagate<RSeir<4, true>>},
+    {DPOMP_BUILTIN_SEIR_FD, 3, 3, k_propagate<RSeir<3, true>>},
+    {DPOMP_BUILTIN_LOTKA, 2, 3, k_propagate<RLotka>},
+    {DPOMP_BUILTIN_ROSSMAC, 4, 6, k_propagate<RRossmac>},
+};
+
+PropFn generic_fn(int S, int E) {
+    const int s = S <= 2 ? 2 : (S <= 4 ? 4 : 8);
+    const int e = E <= 2 ? 2 : (E <= 4 ? 4 : 8);
+#define DPOMP_G(SS, EE) \
+    if (s == SS && e == EE) return k_propagate<RGeneric<SS, EE>>;
+    DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
+    DPOMP_G(8, 4) DPOMP_G(8, 8)
+#undef DPOMP_G
+    return nullptr;
+}
+
+struct KernelStat {
+    int64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingTiming {
+    int kid;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct dpomp_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DevModel dm{};
+    int T = 0;
+    std::vector<double> obs_time;
+    std::vector<int64_t> obs_id;
+    std::vector<long long> ysum;
+    PropFn prop_fn = nullptr;
+    bool prop_is_generic = false;
+    int rs_type = DPOMP_RS_SYSTEMATIC;
+    bool profiling = false;
+    KernelStat stats[KID_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    std::vector<PendingTiming> pending;
+    uint64_t last_events = 0;
+    std::string err;
+    // scratch for dpomp_pf_loglik
+    dpomp_pop* scratch_pop = nullptr;
+};
+
+struct dpomp_pop {
+    int64_t B = 0, P = 0, Pp = 0;
+    int nblk = 0, S = 0, K = 0, T = 0;
+    int32_t* state[2] = {nullptr, nullptr};
+    int cur = 0;
+    double* logw = nullptr;
+    int32_t* offs = nullptr;
+    unsigned long long* blocksum = nullptr;
+    unsigned long long* blockprefix = nullptr;
+    unsigned long long* segmax = nullptr;  // [T][B]
+    unsigned long long* wtot = nullptr;    // [B]
+    double* ll = nullptr;                  // [B]
+    uint32_t* status = nullptr;            // [B]
+    double* theta = nullptr;               // [B][K]
+    unsigned long long* events = nullptr;  // [1]
+    int64_t* ancestors = nullptr;          // [B]
+    bool initialised = false;
+    int last_weighted_obs = -1;
+};
+
+namespace {
+
+int fail(dpomp_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_global_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(h, e_ == hipErrorOutOfMemory ? DPOMP_ENOMEM : DPOMP_EDEVICE, "%s: %s", \
+                        #expr, hipGetErrorString(e_));                                         \
+    } while (0)
+
+hipEvent_t next_event(dpomp_handle* h) {
+    if (h->events_used == h->event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->event_pool.push_back(e);
+    }
+    return h->event_pool[h->events_used++];
+}
+
+struct ScopedTiming {
+    dpomp_handle* h;
+    int kid;
+    hipEvent_t e0 = nullptr;
+    ScopedTiming(dpomp_handle* h_, int kid_) : h(h_), kid(kid_) {
+        if (h->profiling) {
+            e0 = next_event(h);
+            if (e0) (void)hipEventRecord(e0, h->stream);
+        }
+    }
+    ~ScopedTiming() {
+        if (h->profiling && e0) {
+            hipEvent_t e1 = next_event(h);
+            if (e1) {
+                (void)hipEventRecord(e1, h->stream);
+                h->pending.push_back({kid, e0, e1});
+            }
+        }
+    }
+};
+
+void collect_timings(dpomp_handle* h) {
+    for (const PendingTiming& p : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            h->stats[p.kid].launches += 1;
+            h->stats[p.kid].total_ms += ms;
+        }
+    }
+    h->pending.clear();
+    h->events_used = 0;
+}
+
+int validate_desc(const dpomp_model_desc* d) {
+    if (!d) return fail(nullptr, DPOMP_EINVAL, "descriptor is NULL");
+    if (d->abi_version != DPOMP_ABI_VERSION)
+        return fail(nullptr, DPOMP_EINVAL, "abi_version %d, library speaks %d", d->abi_version, DPOMP_ABI_VERSION);
+    if (d->n_states < 1 || d->n_states > DPOMP_MAX_STATES) return fail(nullptr, DPOMP_EINVAL, "n_states %d out of 1..%d", d->n_states, DPOMP_MAX_STATES);
+    if (d->n_events < 1 || d->n_events > DPOMP_MAX_EVENTS) return fail(nullptr, DPOMP_EINVAL, "n_events %d out of 1..%d", d->n_events, DPOMP_MAX_EVENTS);
+    if (d->n_params < 1 || d->n_params > DPOMP_MAX_PARAMS) return fail(nullptr, DPOMP_EINVAL, "n_params %d out of 1..%d", d->n_params, DPOMP_MAX_PARAMS);
+    if (d->t0_index < 0 || d->t0_index > d->n_params) return fail(nullptr, DPOMP_EINVAL, "t0_index %d out of 0..%d", d->t0_index, d->n_params);
+    if (d->n_obs < 1 || !d->obs_time || !d->obs_id) return fail(nullptr, DPOMP_EINVAL, "no observations");
+    if (d->n_obs_values < 0 || d->n_obs_values > 32 || (d->n_obs_values > 0 && !d->obs_value))
+        return fail(nullptr, DPOMP_EINVAL, "n_obs_values %d invalid", d->n_obs_values);
+    if (d->obs.kind != DPOMP_OBS_GAUSSIAN) return fail(nullptr, DPOMP_EINVAL, "unknown observation model kind %d", d->obs.kind);
+    if (!(d->obs.sigma > 0.0)) return fail(nullptr, DPOMP_EINVAL, "obs.sigma must be positive");
+    if (d->obs.state_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "obs.state_mask names a state >= n_states");
+    if (d->n_obs_values < 32 && (d->obs.value_mask >> d->n_obs_values)) return fail(nullptr, DPOMP_EINVAL, "obs.value_mask names a value column >= n_obs_values");
+    for (int s = 0; s < d->n_states; ++s)
+        if (d->initial_condition[s] < 0 || d->initial_condition[s] >= ((int64_t)1 << 30))
+            return fail(nullptr, DPOMP_EINVAL, "initial_condition[%d] out of 0..2^30", s);
+    for (int e = 0; e < d->n_events; ++e) {
+        const dpomp_rate_term& t = d->rate[e];
+        if (t.theta_index < 0 || t.theta_index >= d->n_params) return fail(nullptr, DPOMP_EINVAL, "rate[%d].theta_index out of range", e);
+        if (t.form != DPOMP_RATE_LEFT && t.form != DPOMP_RATE_RATIO) return fail(nullptr, DPOMP_EINVAL, "rate[%d].form unknown", e);
+        if (t.n_factors < 0 || t.n_factors > DPOMP_MAX_FACTORS) return fail(nullptr, DPOMP_EINVAL, "rate[%d].n_factors out of range", e);
+        for (int f = 0; f < t.n_factors; ++f)
+            if (t.factor_mask[f] == 0 || (t.factor_mask[f] >> d->n_states)) return fail(nullptr, DPOMP_EINVAL, "rate[%d].factor_mask[%d] invalid", e, f);
+        if (t.denom_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "rate[%d].denom_mask invalid", e);
+        for (int s = 0; s < d->n_states; ++s)
+            if (d->transition[e][s] < -127 || d->transition[e][s] > 127) return fail(nullptr, DPOMP_EINVAL, "transition[%d][%d] out of int8 range", e, s);
+    }
+    for (int t = 1; t < d->n_obs; ++t)
+        if (d->obs_time[t] < d->obs_time[t - 1]) return fail(nullptr, DPOMP_EINVAL, "obs_time must be non-decreasing");
+    return DPOMP_OK;
+}
+
+void pop_release(dpomp_pop* p) {
+    if (!p) return;
+    for (int i = 0; i < 2; ++i) (void)hipFree(p->state[i]);
+    (void)hipFree(p->logw);
+    (void)hipFree(p->offs);
+    (void)hipFree(p->blocksum);
+    (void)hipFree(p->blockprefix);
+    (void)hipFree(p->segmax);
+    (void)hipFree(p->wtot);
+    (void)hipFree(p->ll);
+    (void)hipFree(p->status);
+    (void)hipFree(p->theta);
+    (void)hipFree(p->events);
+    (void)hipFree(p->ancestors);
+    delete p;
+}
+
+int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
+    if (B < 1 || P < 1 || P >= ((int64_t)1 << 31) - kTile) return fail(h, DPOMP_EINVAL, "B=%lld P=%lld out of range", (long long)B, (long long)P);
+    if (B > 65535) return fail(h, DPOMP_EINVAL, "B=%lld exceeds 65535 segments per call", (long long)B);
+    HIPCHK(h, hipSetDevice(h->device));
+    dpomp_pop* p = new dpomp_pop;
+    p->B = B;
+    p->P = P;
+    p->Pp = (P + kTile - 1) / kTile * kTile;
+    p->nblk = (int)(p->Pp / kTile);
+    p->S = h->dm.S;
+    p->K = h->dm.K;
+    p->T = h->T;
+    const size_t n_state = (size_t)B * p->S * p->Pp;
+#define DPOMP_ALLOC(ptr, bytes)                                                    \
+    do {                                                                           \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                        \
+        if (e_ != hipSuccess) {                                                    \
+            pop_release(p);                                                        \
+            return fail(h, DPOMP_ENOMEM, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                          \
+    } while (0)
+    DPOMP_ALLOC(p->state[0], n_state * sizeof(int32_t));
+    DPOMP_ALLOC(p->state[1], n_state * sizeof(int32_t));
+    DPOMP_ALLOC(p->logw, (size_t)B * p->Pp * sizeof(double));
+    DPOMP_ALLOC(p->offs, (size_t)B * p->Pp * sizeof(int32_t));
+    DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
+    DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
+    DPOMP_ALLOC(p->segmax, (size_t)p->T * B * 8);
+    DPOMP_ALLOC(p->wtot, (size_t)B * 8);
+    DPOMP_ALLOC(p->ll, (size_t)B * 8);
+    DPOMP_ALLOC(p->status, (size_t)B * 4);
+    DPOMP_ALLOC(p->theta, (size_t)B * p->K * 8);
+    DPOMP_ALLOC(p->events, 8);
+    DPOMP_ALLOC(p->ancestors, (size_t)B * 8);
+#undef DPOMP_ALLOC
+    *out = p;
+    return DPOMP_OK;
+}
+
+// The sequencer.  ymin/ymax 1-based as in the reference.
+int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, int ymax, uint64_t seed,
+                int64_t seg_base, uint32_t domain, double* out_ll, uint32_t* out_status,
+                int32_t* record_states /* device [T][B][S][Pp] or null */) {
+    const int T = h->T;
+    if (!theta) return fail(h, DPOMP_EINVAL, "theta is NULL");
+    if (ymin < 1 || ymax > T || ymin > ymax) return fail(h, DPOMP_EINVAL, "ymin=%d ymax=%d out of 1..%d", ymin, ymax, T);
+    if (ymin > 1 && !p->initialised) return fail(h, DPOMP_ESTATE, "ymin=%d on a population that was never initialised (call with ymin=1 or upload first)", ymin);
+    if (seg_base < 0 || seg_base + p->B > 0xFFFFFFFFll) return fail(h, DPOMP_EINVAL, "seg_base out of range");
+    if (h->rs_type != DPOMP_RS_SYSTEMATIC) return fail(h, DPOMP_EINVAL, "resampler %d is not implemented yet (only systematic)", h->rs_type);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int64_t B = p->B;
+    const dim3 block(kBlock);
+    const dim3 grid_tiles((unsigned)p->nblk, (unsigned)B);
+
+    HIPCHK(h, hipMemcpyAsync(p->theta, theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(h, hipMemsetAsync(p->segmax, 0, (size_t)p->T * B * 8, st));
+    HIPCHK(h, hipMemsetAsync(p->ll, 0, (size_t)B * 8, st));
+    HIPCHK(h, hipMemsetAsync(p->status, 0, (size_t)B * 4, st));
+    HIPCHK(h, hipMemsetAsync(p->events, 0, 8, st));
+
+    if (ymin == 1) {  // pop[i,:] .= initial_condition  (:41-45)
+        ScopedTiming tm(h, KID_INIT);
+        hipLaunchKernelGGL(k_init, grid_tiles, block, 0, st, h->dm, p->state[p->cur], p->Pp);
+        p->initialised = true;
+    }
+    double t_prev = (ymin == 1) ? 0.0 : h->obs_time[ymin - 2];  // :45-47
+
+    for (int obs_i = ymin; obs_i <= ymax; ++obs_i) {  // :54
+        const int k = obs_i - 1;
+        const bool weighted = h->obs_id[k] > 0 && domain == DOMAIN_PROPAGATE;  // :58
+        PropArgs a;
+        a.m = h->dm;
+        a.state = p->state[p->cur];
+        a.logw = p->logw;
+        a.theta = p->theta;
+        a.segmax = p->segmax + (size_t)k * B;
+        a.events = p->events;
+        a.status = p->status;
+        a.Pp = p->Pp;
+        a.P = (int32_t)p->P;
+        a.obs_k = (uint32_t)k;
+        a.seg_base = (uint32_t)seg_base;
+        a.domain = domain;
+        a.seed = seed;
+        a.t_prev = t_prev;
+        a.t_max = h->obs_time[k];
+        a.ysum = h->ysum[k];
+        a.use_theta_t0 = (obs_i == 1 && h->dm.t0_index > 0) ? 1 : 0;
+        a.want_weight = weighted ? 1 : 0;
+        {
+            ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
+            hipLaunchKernelGGL(h->prop_fn, dim3((unsigned)((p->P + kBlock - 1) / kBlock), (unsigned)B), block, 0, st, a);
+        }
+        if (record_states)
+            HIPCHK(h, hipMemcpyAsync(record_states + (size_t)k * B * p->S * p->Pp, p->state[p->cur],
+                                     (size_t)B * p->S * p->Pp * 4, hipMemcpyDeviceToDevice, st));
+        if (weighted) {
+            p->last_weighted_obs = k;
+            WeightArgs w;
+            w.logw = p->logw;
+            w.segmax = p->segmax + (size_t)k * B;
+            w.blocksum = p->blocksum;
+            w.blockprefix = p->blockprefix;
+            w.wtot = p->wtot;
+            w.ll = p->ll;
+            w.status = p->status;
+            w.offs = p->offs;
+            w.Pp = p->Pp;
+            w.P = (int32_t)p->P;
+            w.nblk = p->nblk;
+            w.sh = weight_shift(p->P);
+            w.obs_k = (uint32_t)k;
+            w.seg_base = (uint32_t)seg_base;
+            w.seed = seed;
+            {
+                ScopedTiming tm(h, KID_WSUM);
+                hipLaunchKernelGGL(k_wsum, grid_tiles, block, 0, st, w);
+            }
+            {
+                ScopedTiming tm(h, KID_SCAN_BLOCKS);  // output += log(cum_weight[end]/P)  :60
+                hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)B), block, 0, st, w);
+            }
+            if (obs_i < T) {  // :62  (the ESS criterion is commented out in the reference, :63-68)
+                {
+                    ScopedTiming tm(h, KID_OFFSETS);
+                    hipLaunchKernelGGL(k_offsets, grid_tiles, block, 0, st, w);
+                }
+                GatherArgs g;
+                g.src = p->state[p->cur];
+                g.dst = p->state[p->cur ^ 1];
+                g.offs = p->offs;
+                g.Pp = p->Pp;
+                g.P = (int32_t)p->P;
+                g.S = p->S;
+                {
+                    ScopedTiming tm(h, KID_GATHER);  // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67
+                    hipLaunchKernelGGL(k_gather, grid_tiles, block, 0, st, g);
+                }
+                p->cur ^= 1;
+            }
+        }
+        t_prev = h->obs_time[k];  // :72
+    }
+    HIPCHK(h, hipGetLastError());
+    std::vector<uint32_t> status_host((size_t)B);
+    unsigned long long events = 0;
+    if (out_ll) HIPCHK(h, hipMemcpyAsync(out_ll, p->ll, (size_t)B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(status_host.data(), p->status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(&events, p->events, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    collect_timings(h);
+    h->last_events = events;
+    if (out_status) memcpy(out_status, status_host.data(), (size_t)B * 4);
+    return DPOMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpomp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* dpomp_version(void) { return "dpomp-hip 0.1 (gfx950, abi 1)"; }
+
+const char* dpomp_last_global_error(void) { return g_global_error.c_str(); }
+
+int dpomp_create(const dpomp_model_desc* d, int device, dpomp_handle** out) {
+    if (!out) return fail(nullptr, DPOMP_EINVAL, "out is NULL");
+    *out = nullptr;
+    int rc = validate_desc(d);
+    if (rc != DPOMP_OK) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, DPOMP_EDEVICE, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, DPOMP_EINVAL, "device %d out of 0..%d", device, ndev - 1);
+    dpomp_handle* h = new dpomp_handle;
+    h->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rc = fail(nullptr, DPOMP_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
+        delete h;
+        return rc;
+    }
+    h->stream = h->own_stream;
+    h->T = d->n_obs;
+    h->obs_time.assign(d->obs_time, d->obs_time + d->n_obs);
+    h->obs_id.assign(d->obs_id, d->obs_id + d->n_obs);
+    h->ysum.resize(d->n_obs);
+    for (int t = 0; t < d->n_obs; ++t) {  // sum(y.val[y_seq])  hmm_examples.jl:64
+        long long s = 0;
+        for (int v = 0; v < d->n_obs_values; ++v)
+            if (d->obs.value_mask & (1u << v)) s += d->obs_value[(int64_t)t * d->n_obs_values + v];
+        h->ysum[t] = s;
+    }
+    DevModel& m = h->dm;
+    m.S = d->n_states;
+    m.E = d->n_events;
+    m.K = d->n_params;
+    m.t0_index = d->t0_index;
+    m.obs_state_mask = d->obs.state_mask;
+    int64_t cap = d->max_events_per_interval > 0 ? d->max_events_per_interval : ((int64_t)1 << 22);
+    if (cap > 0x7FFFFFFF) cap = 0x7FFFFFFF;
+    m.cap = (int32_t)cap;
+    m.obs_tmp1 = std::log(1.0 / (std::sqrt(2.0 * M_PI) * d->obs.sigma));  // hmm_examples.jl:61
+    m.obs_tmp2 = 2.0 * d->obs.sigma * d->obs.sigma;                        // :62
+    for (int ev = 0; ev < 8; ++ev) {
+        uint64_t w = 0;
+        if (ev < d->n_events)
+            for (int s = 0; s < d->n_states; ++s) w |= (uint64_t)(uint8_t)(int8_t)d->transition[ev][s] << (8 * s);
+        m.trans_packed[ev] = w;
+        const dpomp_rate_term& t = d->rate[ev < d->n_events ? ev : 0];
+        m.rate[ev] = {t.theta_index, t.form, t.n_factors, t.factor_mask[0], t.factor_mask[1], t.denom_mask};
+        m.x0[ev] = ev < d->n_states ? (int32_t)d->initial_condition[ev] : 0;
+    }
+    h->prop_fn = nullptr;
+    for (const PropEntry& pe : kPropTable)
+        if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop_fn = pe.fn;
+    if (!h->prop_fn) {
+        h->prop_fn = generic_fn(d->n_states, d->n_events);
+        h->prop_is_generic = true;
+    }
+    *out = h;
+    return DPOMP_OK;
+}
+
+void dpomp_destroy(dpomp_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->scratch_pop) pop_release(h->scratch_pop);
+    for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+const char* dpomp_last_error(const dpomp_handle* h) { return h ? h->err.c_str() : g_global_error.c_str(); }
+
+int dpomp_set_stream(dpomp_handle* h, void* hip_stream) {
+    if (!h) return DPOMP_EINVAL;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return DPOMP_OK;
+}
+
+int dpomp_set_resampler(dpomp_handle* h, int rs_type) {
+    if (!h) return DPOMP_EINVAL;
+    if (rs_type < DPOMP_RS_SYSTEMATIC || rs_type > DPOMP_RS_MULTINOMIAL) return fail(h, DPOMP_EINVAL, "rs_type %d unknown", rs_type);
+    h->rs_type = rs_type;
+    return DPOMP_OK;
+}
+
+int dpomp_pop_alloc(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
+    if (!h || !out) return DPOMP_EINVAL;
+    *out = nullptr;
+    return pop_alloc_impl(h, B, P, out);
+}
+
+void dpomp_pop_free(dpomp_handle* h, dpomp_pop* pop) {
+    if (h) (void)hipSetDevice(h->device);
+    pop_release(pop);
+}
+
+int dpomp_pf_partial(dpomp_handle* h, dpomp_pop* pop, const double* theta, int32_t ymin, int32_t ymax,
+                     uint64_t seed, int64_t seg_base, double* out_ll, uint32_t* out_status) {
+    if (!h) return DPOMP_EINVAL;
+    if (!pop || !out_ll) return fail(h, DPOMP_EINVAL, "pop or out_ll is NULL");
+    return run_partial(h, pop, theta, ymin, ymax, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
+}
+
+int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
+                    int64_t seg_base, double* out_ll, uint32_t* out_status) {
+    if (!h) return DPOMP_EINVAL;
+    if (!out_ll) return fail(h, DPOMP_EINVAL, "out_ll is NULL");
+    if (!h->scratch_pop || h->scratch_pop->B != B || h->scratch_pop->P != P) {
+        if (h->scratch_pop) {
+            pop_release(h->scratch_pop);
+            h->scratch_pop = nullptr;
+        }
+        int rc = pop_alloc_impl(h, B, P, &h->scratch_pop);
+        if (rc != DPOMP_OK) return rc;
+    }
+    return run_partial(h, h->scratch_pop, theta, 1, h->T, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
+}
+
+int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
+    if (!h) return DPOMP_EINVAL;
+    if (!p || !ancestors) return fail(h, DPOMP_EINVAL, "pop or ancestors is NULL");
+    for (int64_t b = 0; b < p->B; ++b)
+        if (ancestors[b] < 0 || ancestors[b] >= p->B) return fail(h, DPOMP_EINVAL, "ancestors[%lld]=%lld out of range", (long long)b, (long long)ancestors[b]);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(p->ancestors, ancestors, (size_t)p->B * 8, hipMemcpyHostToDevice, h->stream));
+    const int64_t seg_ints = (int64_t)p->S * p->Pp;
+    {
+        ScopedTiming tm(h, KID_COPYSEG);
+        hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)p->B), dim3(kBlock), 0,
+                           h->stream, (const int32_t*)p->state[p->cur], p->state[p->cur ^ 1], (const int64_t*)p->ancestors, seg_ints);
+    }
+    p->cur ^= 1;
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    collect_timings(h);
+    return DPOMP_OK;
+}
+
+int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* p, int64_t b, int64_t* out) {
+    if (!h) return DPOMP_EINVAL;
+    if (!p || !out || b < 0 || b >= p->B) return fail(h, DPOMP_EINVAL, "bad pop/out/b");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int32_t> tmp((size_t)p->S * p->Pp);
+    HIPCHK(h, hipMemcpyAsync(tmp.data(), p->state[p->cur] + (size_t)b * p->S * p->Pp, tmp.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int s = 0; s < p->S; ++s)
+        for (int64_t i = 0; i < p->P; ++i) out[i + p->P * s] = tmp[(size_t)s * p->Pp + i];
+    return DPOMP_OK;
+}
+
+int dpomp_pop_upload(dpomp_handle* h, dpomp_pop* p, int64_t b, const int64_t* in) {
+    if (!h) return DPOMP_EINVAL;
+    if (!p || !in || b < 0 || b >= p->B) return fail(h, DPOMP_EINVAL, "bad pop/in/b");
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int32_t> tmp((size_t)p->S * p->Pp, 0);
+    for (int s = 0; s < p->S; ++s)
+        for (int64_t i = 0; i < p->P; ++i) {
+            const int64_t v = in[i + p->P * s];
+            if (v < 0 || v >= ((int64_t)1 << 30)) return fail(h, DPOMP_EINVAL, "state value %lld out of 0..2^30", (long long)v);
+            tmp[(size_t)s * p->Pp + i] = (int32_t)v;
+        }
+    HIPCHK(h, hipMemcpyAsync(p->state[p->cur] + (size_t)b * p->S * p->Pp, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    p->initialised = true;
+    return DPOMP_OK;
+}
+
+int dpomp_simulate(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed, int64_t seg_base, int64_t* out) {
+    if (!h) return DPOMP_EINVAL;
+    if (!out) return fail(h, DPOMP_EINVAL, "out is NULL");
+    dpomp_pop* p = nullptr;
+    int rc = pop_alloc_impl(h, B, P, &p);
+    if (rc != DPOMP_OK) return rc;
+    int32_t* rec = nullptr;
+    const size_t n = (size_t)h->T * B * p->S * p->Pp;
+    if (hipMalloc((void**)&rec, n * 4) != hipSuccess) {
+        pop_release(p);
+        return fail(h, DPOMP_ENOMEM, "hipMalloc(%zu) for the simulation record", n * 4);
+    }
+    rc = run_partial(h, p, theta, 1, h->T, seed, seg_base, DOMAIN_SIMULATE, nullptr, nullptr, rec);
+    if (rc == DPOMP_OK) {
+        std::vector<int32_t> tmp(n);
+        hipError_t e = hipMemcpy(tmp.data(), rec, n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(h, DPOMP_EDEVICE, "hipMemcpy: %s", hipGetErrorString(e));
+        else
+            for (int t = 0; t < h->T; ++t)
+                for (int64_t b = 0; b < B; ++b)
+                    for (int s = 0; s < p->S; ++s)
+                        for (int64_t i = 0; i < P; ++i)
+                            out[((b * h->T + t) * p->S + s) * P + i] = tmp[(((size_t)t * B + b) * p->S + s) * p->Pp + i];
+    }
+    (void)hipFree(rec);
+    pop_release(p);
+    return rc;
+}
+
+int dpomp_debug_download(dpomp_handle* h, const dpomp_pop* p, int what, int64_t b, void* out) {
+    if (!h) return DPOMP_EINVAL;
+    if (!p) p = h->scratch_pop;
+    if (!p || !out || b < 0 || b >= p->B) return fail(h, DPOMP_EINVAL, "bad pop/out/b");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (what == DPOMP_DBG_LOGW) {
+        HIPCHK(h, hipMemcpy(out, p->logw + (size_t)b * p->Pp, (size_t)p->P * 8, hipMemcpyDeviceToHost));
+    } else if (what == DPOMP_DBG_OFFSPRING_END) {
+        HIPCHK(h, hipMemcpy(out, p->offs + (size_t)b * p->Pp, (size_t)p->P * 4, hipMemcpyDeviceToHost));
+    } else {
+        return fail(h, DPOMP_EINVAL, "unknown debug item %d", what);
+    }
+    return DPOMP_OK;
+}
+
+int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const double* x_in, double* out_uniform,
+                            double* out_log, double* out_exp) {
+    if (!h) return DPOMP_EINVAL;
+    if (n < 1) return fail(h, DPOMP_EINVAL, "n < 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    double *dx = nullptr, *du = nullptr, *dl = nullptr, *de = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dx, (size_t)n * 8));
+    HIPCHK(h, hipMalloc((void**)&du, (size_t)n * 8));
+    HIPCHK(h, hipMalloc((void**)&dl, (size_t)n * 8));
+    HIPCHK(h, hipMalloc((void**)&de, (size_t)n * 8));
+    if (x_in) HIPCHK(h, hipMemcpy(dx, x_in, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, seed,
+                       x_in ? (const double*)dx : (const double*)nullptr, du, dl, de);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (out_uniform) HIPCHK(h, hipMemcpy(out_uniform, du, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (out_log && x_in) HIPCHK(h, hipMemcpy(out_log, dl, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (out_exp && x_in) HIPCHK(h, hipMemcpy(out_exp, de, (size_t)n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(du);
+    (void)hipFree(dl);
+    (void)hipFree(de);
+    return DPOMP_OK;
+}
+
+int dpomp_set_profiling(dpomp_handle* h, int on) {
+    if (!h) return DPOMP_EINVAL;
+    h->profiling = on != 0;
+    return DPOMP_OK;
+}
+
+int dpomp_kernel_count(void) { return KID_COUNT; }
+
+const char* dpomp_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? kKernelNames[kid] : ""; }
+
+int dpomp_get_kernel_stat(dpomp_handle* h, int kid, int64_t* launches, double* total_ms) {
+    if (!h || kid < 0 || kid >= KID_COUNT) return DPOMP_EINVAL;
+    if (launches) *launches = h->stats[kid].launches;
+    if (total_ms) *total_ms = h->stats[kid].total_ms;
+    return DPOMP_OK;
+}
+
+int dpomp_last_event_count(dpomp_handle* h, uint64_t* events) {
+    if (!h || !events) return DPOMP_EINVAL;
+    *events = h->last_events;
+    return DPOMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// dpomp_kernels.h -- gfx950 kernels of the bootstrap particle filter.
+//
+//   k_propagate   iterate_particles!   src/hmm_particle_filter.jl:9-33  (+ choose_event
+//                 src/hmm_cmn.jl:4-10, rate functions src/hmm_examples.jl:103-168,
+//                 transition src/hmm_examples.jl:11-16, obs model :59-67)
+//   k_wsum, k_scan_blocks, k_offsets, k_gather
+//                 log mean weight  src/hmm_particle_filter.jl:60  and
+//                 rsp_systematic   src/hmm_pf_resample.jl:24-42
+//
+// Layout in HBM (per population handle): state[b][s][p] int32, p fastest, row stride Pp
+// (P rounded up to the 1024-slot tile) -- the reference's column-major P x S matrix per
+// segment, i.e. structure-of-arrays, so a wave reads 64 consecutive ints per component;
+// logw[b][p] double; offs[b][p] int32 (offspring boundaries N_j).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "dpomp_numerics.h"
+
+namespace dpomp {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 waves of 64)
+constexpr int kItems = 4;          // slots per thread in the streaming kernels
+constexpr int kTile = kBlock * kItems;  // 1024 slots per workgroup
+
+struct DevRateTerm {
+    int32_t theta_index, form, n_factors;
+    uint32_t fmask0, fmask1, dmask;
+};
+
+struct DevModel {
+    int32_t S, E, K;
+    int32_t t0_index;  // 0 = none, else 1-based theta index (DPOMPModel.t0_index)
+    uint32_t obs_state_mask;
+    int32_t cap;       // max events per particle and interval
+    double obs_tmp1, obs_tmp2;  // log(1/(sqrt(2 pi) sigma)), 2 sigma^2
+    uint64_t trans_packed[8];   // m_transition row e as one int8 per state component
+    DevRateTerm rate[8];
+    int32_t x0[8];
+};
+
+struct PropArgs {
+    DevModel m;
+    int32_t* state;              // current population buffer
+    double* logw;
+    const double* theta;         // [B][K]
+    unsigned long long* segmax;  // [B] ordered key of max log-weight (this observation)
+    unsigned long long* events;  // [1]
+    uint32_t* status;            // [B]
+    int64_t Pp;
+    int32_t P;
+    uint32_t obs_k, seg_base, domain;
+    uint64_t seed;
+    double t_prev, t_max;
+    long long ysum;
+    int32_t use_theta_t0;  // first interval of a ymin == 1 call with t0_index > 0
+    int32_t want_weight;
+};
+
+// ---- rate evaluators (the pluggable part) -------------------------------------------------
+// Each evaluator restates one reference rate function with the same association order:
+// Julia's `θ[1] * pop[1] * pop[2]` is ((θ·Float64(x1))·Float64(x2)).
+template <int S_, int E_>
+struct RGeneric {  // interprets DevModel::rate (any model that fits the descriptor)
+    static constexpr int S = S_, E = E_;
+    static constexpr bool kGeneric = true;
+    static __device__ __forceinline__ int msum(uint32_t mask, const int (&x)[S]) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+            if (mask & (1u << i)) s += x[i];
+        return s;
+    }
+    static __device__ __forceinline__ void rates(const DevModel& m, const double* th,
+                                                 const int (&x)[S], double (&r)[E]) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (e < m.E) {
+                const DevRateTerm& t = m.rate[e];
+                const double theta = th[t.theta_index];
+                if (t.form == 0) {
+                    double v = theta;
+                    if (t.n_factors > 0) v = v * (double)msum(t.fmask0, x);
+                    if (t.n_factors > 1) v = v * (double)msum(t.fmask1, x);
+                    if (t.dmask) v = v / (double)msum(t.dmask, x);
+                    r[e] = v;
+                } else {
+                    long long prod = 1;
+                    if (t.n_factors > 0) prod *= (long long)msum(t.fmask0, x);
+                    if (t.n_factors > 1) prod *= (long long)msum(t.fmask1, x);
+                    double q = (double)prod;
+                    if (t.dmask) q = q / (double)msum(t.dmask, x);
+                    r[e] = theta * q;
+                }
+            } else {
+                r[e] = 0.0;
+            }
+        }
+    }
+};
+
+template <int S_, int E_>
+struct RBase {
+    static constexpr int S = S_, E = E_;
+    static constexpr bool kGeneric = false;
+    static __device__ __forceinline__ double total(const int (&x)[S_]) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < S_; ++i) s += x[i];
+        return (double)s;
+    }
+};
+// si_rf / si_rf_fd   hmm_examples.jl:103-105, :126-128
+template <bool FD>
+struct RSi : RBase<2, 1> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[2], double (&r)[1]) {
+        r[0] = th[0] * (double)x[0] * (double)x[1];
+        if (FD) r[0] = r[0] / total(x);
+    }
+};
+// sir_rf / sir_rf_fd   :107-110, :130-133   (SIR: S=3, SIS: S=2)
+template <int S_, bool FD>
+struct RSir : RBase<S_, 2> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[S_], double (&r)[2]) {
+        r[0] = th[0] * (double)x[0] * (double)x[1];
+        if (FD) r[0] = r[0] / RBase<S_, 2>::total(x);
+        r[1] = th[1] * (double)x[1];
+    }
+};
+// sei_rf / sei_rf_fd   :112-115, :135-138
+template <bool FD>
+struct RSei : RBase<3, 2> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[3], double (&r)[2]) {
+        r[0] = th[0] * (double)x[0] * (double)x[2];
+        if (FD) r[0] = r[0] / total(x);
+        r[1] = th[1] * (double)x[1];
+    }
+};
+// seir_rf / seir_rf_fd   :117-121, :140-144   (SEIR: S=4, SEIS: S=3)
+template <int S_, bool FD>
+struct RSeir : RBase<S_, 3> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[S_], double (&r)[3]) {
+        r[0] = th[0] * (double)x[0] * (double)x[2];
+        if (FD) r[0] = r[0] / RBase<S_, 3>::total(x);
+        r[1] = th[1] * (double)x[1];
+        r[2] = th[2] * (double)x[2];
+    }
+};
+// lotka_rf   :149-154
+struct RLotka : RBase<2, 3> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[2], double (&r)[3]) {
+        r[0] = th[0] * (double)x[1];
+        r[1] = th[1] * (double)x[0] * (double)x[1];
+        r[2] = th[2] * (double)x[0];
+    }
+};
+// rossmac_rf   :159-168
+struct RRossmac : RBase<4, 6> {
+    static __device__ __forceinline__ void rates(const DevModel&, const double* th,
+                                                 const int (&x)[4], double (&r)[6]) {
+        r[0] = th[0] * (double)(x[2] + x[3]);
+        r[1] = th[0] * (double)x[2];
+        r[2] = th[0] * (double)x[3];
+        r[3] = th[1] * ((double)((long long)x[0] * (long long)x[3]) / (double)(x[0] + x[1]));
+        r[4] = th[2] * ((double)((long long)x[1] * (long long)x[2]) / (double)(x[2] + x[3]));
+        r[5] = th[3] * (double)x[1];
+    }
+};
+
+// ---- wave / block helpers --------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// ---- k_init: pop[i,:] .= initial_condition   (hmm_particle_filter.jl:42-44) -----------------
+__global__ __launch_bounds__(kBlock) void k_init(DevModel m, int32_t* state, int64_t Pp) {
+    const int64_t b = blockIdx.y;
+    const int64_t p0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kItems;
+    if (p0 >= Pp) return;
+    for (int s = 0; s < m.S; ++s) {
+        const int v = m.x0[s];
+        *reinterpret_cast<int4*>(state + (b * m.S + s) * Pp + p0) = make_int4(v, v, v, v);
+    }
+}
+
+// ---- k_propagate: one particle per lane ------------------------------------------------------
+// Gillespie direct method from t_prev to t_max with state and clock in VGPRs, then the
+// observation log-weight.  Per event: rates -> cumsum -> total == 0 ? -> time -= log(u)/total
+// -> time > tmax ? -> event by inverse CDF (strict >, last event falls through) -> state +=
+// transition row.  Epilogue: state and log-weight back to HBM, workgroup max of the
+// log-weights into segmax (one 64-bit atomicMax per workgroup), event count.
+template <class R>
+__global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
+    constexpr int S = R::S, E = R::E;
+    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < a.P;
+    int32_t* st = a.state + (int64_t)b * S * a.Pp;
+    const double* th = a.theta + (int64_t)b * a.m.K;
+
+    int x[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = valid ? st[(int64_t)s * a.Pp + p] : 0;
+
+    double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
+    const double tmax = a.t_max;
+    Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
+    const int e_real = R::kGeneric ? a.m.E : E;
+    const int cap = a.m.cap;
+    int n = 0;
+    bool capped = false;
+
+    if (valid) {
+        for (;;) {
+            double cum[E];
+            R::rates(a.m, th, x, cum);
+#pragma unroll
+            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+            const double tot = cum[E - 1];
+            if (tot == 0.0) break;
+            const double u1 = u01(stream_next(rng));
+            time = time - dlog(u1) / tot;
+            if (time > tmax) break;
+            const double etc = u01(stream_next(rng)) * tot;
+            TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+            for (int i = E - 2; i >= 0; --i) {
+                const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+            if (++n >= cap) {
+                capped = true;
+                break;
+            }
+        }
+    }
+
+    double g = -__builtin_inf();
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) st[(int64_t)s * a.Pp + p] = x[s];
+        if (a.want_weight) {
+            int xs = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (a.m.obs_state_mask & (1u << s)) xs += x[s];
+            const long long d = a.ysum - (long long)xs;
+            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
+            a.logw[(int64_t)b * a.Pp + p] = g;
+        }
+    }
+
+    __shared__ double s_max[kBlock / 64];
+    __shared__ unsigned long long s_ev[kBlock / 64];
+    __shared__ int s_cap[kBlock / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double wm = wave_max(g);
+    const unsigned long long wev = wave_sum((unsigned long long)n);
+    const int wcap = __any(capped);
+    if (lane == 0) {
+        s_max[wid] = wm;
+        s_ev[wid] = wev;
+        s_cap[wid] = wcap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bm = s_max[0];
+        unsigned long long be = s_ev[0];
+        int bc = s_cap[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) {
+            bm = fmax(bm, s_max[w]);
+            be += s_ev[w];
+            bc |= s_cap[w];
+        }
+        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (be) atomicAdd(a.events, be);
+        if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+    }
+}
+
+// ---- weights -----------------------------------------------------------------------------------
+struct WeightArgs {
+    const double* logw;                 // [B][Pp]
+    const unsigned long long* segmax;   // [B]
+    unsigned long long* blocksum;       // [B][nblk]
+    unsigned long long* blockprefix;    // [B][nblk] exclusive prefix of blocksum
+    unsigned long long* wtot;           // [B]
+    double* ll;                         // [B] running log-likelihood
+    uint32_t* status;                   // [B]
+    int32_t* offs;                      // [B][Pp]
+    int64_t Pp;
+    int32_t P, nblk, sh;
+    uint32_t obs_k, seg_base;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ void load_tile_weights(const WeightArgs& a, int b, int blk,
+                                                  unsigned long long (&w)[kItems]) {
+    const double m = ordered_value(a.segmax[b]);
+    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    const double* src = a.logw + (int64_t)b * a.Pp + i0;
+    const double2 g01 = *reinterpret_cast<const double2*>(src);
+    const double2 g23 = *reinterpret_cast<const double2*>(src + 2);
+    const double g[kItems] = {g01.x, g01.y, g23.x, g23.y};
+#pragma unroll
+    for (int q = 0; q < kItems; ++q) w[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
+}
+
+// k_wsum: per-tile sum of the fixed-point weights rint(exp(g - max) 2^sh).
+__global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    unsigned long long w[kItems];
+    load_tile_weights(a, b, blk, w);
+    unsigned long long t = (w[0] + w[1]) + (w[2] + w[3]);
+    __shared__ unsigned long long s_sum[kBlock / 64];
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.blocksum[(int64_t)b * a.nblk + blk] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+}
+
+// k_scan_blocks: one workgroup per segment; exclusive scan of the tile sums, the total W, and
+// output += log(cum_weight[end] / P)   (hmm_particle_filter.jl:60).
+__global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
+    const int b = blockIdx.x;
+    const int per = (a.nblk + kBlock - 1) / kBlock;
+    const int lo = threadIdx.x * per;
+    const int hi = min(lo + per, a.nblk);
+    const unsigned long long* bs = a.blocksum + (int64_t)b * a.nblk;
+    unsigned long long* bp = a.blockprefix + (int64_t)b * a.nblk;
+    unsigned long long t = 0;
+    for (int i = lo; i < hi; ++i) t += bs[i];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long incl = wave_inclusive_scan(t, lane);
+    __shared__ unsigned long long s_w[kBlock / 64];
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wid; ++w) base += s_w[w];
+    unsigned long long run = base + (incl - t);
+    for (int i = lo; i < hi; ++i) {
+        bp[i] = run;
+        run += bs[i];
+    }
+    if (threadIdx.x == kBlock - 1) {
+        const unsigned long long W = run;
+        a.wtot[b] = W;
+        if (W == 0) {
+            a.ll[b] += -__builtin_inf();
+            atomicOr(&a.status[b], 2u /* DPOMP_ST_ZERO_WEIGHT */);
+        } else {
+            a.ll[b] += log_mean_weight(ordered_value(a.segmax[b]), W, a.sh, a.P);
+        }
+    }
+}
+
+// k_offsets: inclusive fixed-point cumulative weight c_j of every particle (tile scan + tile
+// prefix) -> offspring boundary N_j.  Slots [N_{j-1}, N_j) of the resampled population copy
+// particle j: rsp_systematic's u_i = (u1 + (i-1)/P) cw[end], `while u[i] > cw[j]`
+// (hmm_pf_resample.jl:27-37) solved for i instead of walked.
+__global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
+    const int b = blockIdx.y, blk = blockIdx.x;
+    unsigned long long w[kItems];
+    load_tile_weights(a, b, blk, w);
+    unsigned long long c[kItems];
+    c[0] = w[0];
+#pragma unroll
+    for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + w[q];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
+    __shared__ unsigned long long s_w[kBlock / 64];
+    if (lane == 63) s_w[wid] = incl;
+    __syncthreads();
+    unsigned long long base = a.blockprefix[(int64_t)b * a.nblk + blk] + (incl - c[kItems - 1]);
+    for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
+
+    const unsigned long long W = a.wtot[b];
+    const double Wd = u64_to_double(W);
+    Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
+    const double r = u01(stream_next(rs));  // rand() of hmm_pf_resample.jl:27
+    int n[kItems];
+#pragma unroll
+    for (int q = 0; q < kItems; ++q)
+        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], Wd, a.P, r);
+    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
+}
+
+// ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------
+// Ancestor of slot i = first j with N_j > i (binary search over the monotone boundaries).
+// Writes are 16 B per lane per component; reads are monotone in i.
+struct GatherArgs {
+    const int32_t* src;  // [B][S][Pp]
+    int32_t* dst;
+    const int32_t* offs;  // [B][Pp]
+    int64_t Pp;
+    int32_t P, S;
+};
+
+__device__ __forceinline__ int first_greater(const int32_t* __restrict__ N, int P, int i) {
+    int lo = 0, hi = P - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (N[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
+    const int b = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * kTile + threadIdx.x * kItems;
+    const int32_t* N = a.offs + (int64_t)b * a.Pp;
+    int j[kItems];
+#pragma unroll
+    for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? first_greater(N, a.P, (int)(i0 + q)) : 0;
+    for (int s = 0; s < a.S; ++s) {
+        const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
+        const int4 v = make_int4(src[j[0]], src[j[1]], src[j[2]], src[j[3]]);
+        *reinterpret_cast<int4*>(a.dst + ((int64_t)b * a.S + s) * a.Pp + i0) = v;
+    }
+}
+
+// ---- k_copy_segments: pop[b] <- pop[ancestors[b]]   (hmm_ibis.jl:71-75) ---------------------------
+__global__ __launch_bounds__(kBlock) void k_copy_segments(const int32_t* src, int32_t* dst,
+                                                          const int64_t* ancestors, int64_t seg_ints) {
+    const int64_t b = blockIdx.y;
+    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kItems;
+    if (i0 >= seg_ints) return;
+    const int64_t a = ancestors[b];
+    *reinterpret_cast<int4*>(dst + b * seg_ints + i0) =
+        *reinterpret_cast<const int4*>(src + a * seg_ints + i0);
+}
+
+// ---- k_selftest: device evaluation of the shared numerics ----------------------------------------
+__global__ void k_selftest(int64_t n, uint64_t seed, const double* x, double* out_u, double* out_log,
+                           double* out_exp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (out_u) {
+        Stream s = stream_init(seed, 0u, (uint32_t)i, 0u, DOMAIN_PROPAGATE);
+        out_u[i] = u01(stream_next(s));
+    }
+    if (x && out_log) out_log[i] = dlog(x[i]);
+    if (x && out_exp) out_exp[i] = dexp(-37.0 * x[i]);
+}
+
+}  // namespace dpomp

@@ -1,0 +1,193 @@
+// dpomp_numerics.h -- the numerical spec shared by every kernel: counter-based
+// RNG streams, (0,1) uniforms, dlog/dexp, fixed-point weights and offspring
+// boundaries (DESIGN.md "Numerical spec").  Every routine is a fixed sequence
+// of IEEE-754 double operations (fma = one rounding; the translation unit is
+// built with -ffp-contract=off so nothing else fuses), so a CPU evaluation of
+// the same spec gives the same bits.  Compiles for gfx950 (hipcc) and, for the
+// host-side bit check in tests/test_numerics_host.py, as plain C++.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DPOMP_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstring>
+#define DPOMP_HD static inline
+#endif
+
+namespace dpomp {
+
+enum : uint32_t {
+    DOMAIN_PROPAGATE = 0u,          // per-particle Gillespie stream of one interval
+    DOMAIN_RESAMPLE = 1u,           // the single systematic-resampling uniform of one observation
+    DOMAIN_SIMULATE = 2u,           // forward simulation (dpomp_simulate)
+    DOMAIN_RESAMPLE_PARTICLE = 3u,  // per-slot uniforms of the stratified / multinomial resamplers
+};
+
+DPOMP_HD double bits_to_double(uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)b);
+#else
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return d;
+#endif
+}
+DPOMP_HD uint64_t double_to_bits(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)__double_as_longlong(d);
+#else
+    uint64_t b;
+    __builtin_memcpy(&b, &d, 8);
+    return b;
+#endif
+}
+
+struct Stream {
+    uint64_t s0, s1;
+};
+
+// Philox4x32-10 keyed by the call seed; counter = (particle, segment, observation, domain).
+DPOMP_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                            uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+DPOMP_HD Stream stream_init(uint64_t seed, uint32_t seg, uint32_t particle, uint32_t obs,
+                            uint32_t domain) {
+    uint32_t o[4];
+    philox4x32_10(particle, seg, obs, domain, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    Stream s;
+    s.s0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+    s.s1 = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
+    if ((s.s0 | s.s1) == 0) s.s0 = 0x9E3779B97F4A7C15ull;
+    return s;
+}
+
+DPOMP_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+// xoroshiro128++ step.
+DPOMP_HD uint64_t stream_next(Stream& s) {
+    const uint64_t s0 = s.s0;
+    uint64_t s1 = s.s1;
+    const uint64_t result = rotl64(s0 + s1, 17) + s0;
+    s1 ^= s0;
+    s.s0 = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
+    s.s1 = rotl64(s1, 28);
+    return result;
+}
+
+// Top 52 bits -> u = (2k+1) 2^-53 in (0,1).  [1,2) mantissa trick: (d - 1) = k 2^-52 exactly,
+// and k 2^-52 + 2^-53 is representable, so this equals (double)(2k+1) * 2^-53 bit for bit.
+DPOMP_HD double u01(uint64_t x) {
+    const double d = bits_to_double(0x3FF0000000000000ull | (x >> 12));
+    return (d - 1.0) + 0x1p-53;
+}
+
+// log(x), positive normal x.  x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2); s = f/(2+f);
+// log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)), R the degree-7 minimax of the fdlibm family.
+DPOMP_HD double dlog(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const uint64_t bits = double_to_bits(x);
+    uint32_t hx = (uint32_t)(bits >> 32);
+    const uint32_t lx = (uint32_t)bits;
+    int32_t k = (int32_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    hx |= i ^ 0x3ff00000u;
+    k += (int32_t)(i >> 20);
+    const double m = bits_to_double(((uint64_t)hx << 32) | lx);
+    const double f = m - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    const double a = __builtin_fma(dk, ln2_lo, s * (hfsq + R));
+    const double b = (a - hfsq) + f;
+    return __builtin_fma(dk, ln2_hi, b);
+}
+
+// exp(x), -37 <= x <= 0.
+DPOMP_HD double dexp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01,
+                 P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    const int32_t k = (int32_t)(invln2 * x - 0.5);
+    const double t = (double)k;
+    const double hi = x - t * ln2HI;
+    const double lo = t * ln2LO;
+    const double r = hi - lo;
+    const double tt = r * r;
+    const double c = r - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return bits_to_double(double_to_bits(y) + ((uint64_t)(int64_t)k << 52));
+}
+
+DPOMP_HD double u64_to_double(uint64_t v) {
+    return (double)(uint32_t)(v >> 32) * 4294967296.0 + (double)(uint32_t)v;
+}
+
+DPOMP_HD int weight_shift(int64_t P) {
+    int n = 0;
+    while (((int64_t)1 << n) < P) ++n;
+    const int sh = 62 - n;
+    return sh > 52 ? 52 : sh;
+}
+
+// Max-shifted weight as fixed point: rint(exp(g - m) 2^sh); 0 for -inf/NaN and below e^-37.
+DPOMP_HD uint64_t fixed_weight(double g, double m, int sh) {
+    if (!(g > -__builtin_inf())) return 0;
+    const double x = g - m;
+    if (x < -37.0) return 0;
+    return (uint64_t)__builtin_rint(dexp(x) * (double)((uint64_t)1 << sh));
+}
+
+// Offspring boundary N(c) = clamp(ceil(c/W P - r), 0, P): slots [N(c_{j-1}), N(c_j)) copy particle j.
+DPOMP_HD int64_t offspring_end(uint64_t c, double Wd, int64_t P, double r) {
+    const double pos = (u64_to_double(c) / Wd) * (double)P - r;
+    const double n = __builtin_ceil(pos);
+    if (!(n > 0.0)) return 0;
+    if (n > (double)P) return P;
+    return (int64_t)n;
+}
+
+// log mean weight of one observation: m + log((W 2^-sh) / P), i.e. log(cum_weight[end]/P)
+// of hmm_particle_filter.jl:60 with the max factored out.
+DPOMP_HD double log_mean_weight(double m, uint64_t W, int sh, int64_t P) {
+    const double Wd = u64_to_double(W);
+    return m + dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
+}
+
+// Order-preserving u64 key of a double, for integer atomicMax; key 0 sorts below every value.
+DPOMP_HD uint64_t ordered_key(double d) {
+    const uint64_t b = double_to_bits(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+DPOMP_HD double ordered_value(uint64_t key) {
+    if (key == 0) return -__builtin_inf();
+    return bits_to_double((key >> 63) ? (key & 0x7FFFFFFFFFFFFFFFull) : ~key);
+}
+
+}  // namespace dpomp

@@ -1,0 +1,222 @@
+"""The particle filter operator: host mirror of src/hmm_particle_filter.jl over the C ABI.
+
+* ``get_particle_filter_lpdf``  src/hmm_utils.jl:281-284  -> closure theta -> log p^(y | theta)
+* ``get_log_pdf_fn``            src/hmm_particle_filter.jl:87-101
+* ``estimate_likelihood``       src/hmm_particle_filter.jl:79-84
+* ``partial_log_likelihood``    src/hmm_particle_filter.jl:39-76 (on a device-resident population)
+
+All arithmetic happens in libdpomp_hip.so on the GPU; this module only marshals arguments.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .model import DPOMPModel, ModelDescriptor, Observation
+
+# defaults of the reference (src/DiscretePOMP.jl:50-52)
+C_DF_PF_P = 200
+C_DF_ESS_CRIT = 0.3
+
+
+class DpompError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"dpomp error {code}: {message}")
+        self.code = code
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Population:
+    """Device-resident populations of B independent filters (the ``pop::Array{Int64,2}`` that
+    ``run_pibis`` keeps per theta-particle, src/hmm_ibis.jl:26-30)."""
+
+    def __init__(self, pf: "ParticleFilter", B: int, P: int):
+        self._pf = pf
+        self.B, self.P = int(B), int(P)
+        self._ptr = C.c_void_p()
+        pf._check(pf._lib.dpomp_pop_alloc(pf._h, self.B, self.P, C.byref(self._ptr)))
+
+    def close(self):
+        if self._ptr and self._pf._h:
+            self._pf._lib.dpomp_pop_free(self._pf._h, self._ptr)
+            self._ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def download(self, b: int = 0) -> np.ndarray:
+        """Segment ``b`` as a P x S Int64 matrix (rows = particles), like the reference's ``pop``."""
+        S = self._pf.n_states
+        out = np.empty((S, self.P), dtype=np.int64)  # column-major P x S == C-order S x P
+        self._pf._check(self._pf._lib.dpomp_pop_download(self._pf._h, self._ptr, b,
+                                                         out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out.T
+
+    def upload(self, b: int, pop: np.ndarray):
+        S = self._pf.n_states
+        arr = np.ascontiguousarray(np.asarray(pop, dtype=np.int64).T)
+        if arr.shape != (S, self.P):
+            raise ValueError(f"expected a {self.P} x {S} matrix")
+        self._pf._check(self._pf._lib.dpomp_pop_upload(self._pf._h, self._ptr, b,
+                                                       arr.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def gather(self, ancestors: Sequence[int]):
+        """``pop[b] <- pop[ancestors[b]]`` (0-based), the theta-level resampling copy of
+        src/hmm_ibis.jl:71-75."""
+        a = np.ascontiguousarray(ancestors, dtype=np.int64)
+        if a.shape != (self.B,):
+            raise ValueError("one ancestor per segment")
+        self._pf._check(self._pf._lib.dpomp_pop_gather(self._pf._h, self._ptr, a.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    def debug(self, what: int, b: int = 0) -> np.ndarray:
+        out = np.empty(self.P, dtype=np.float64 if what == _abi.DBG_LOGW else np.int32)
+        self._pf._check(self._pf._lib.dpomp_debug_download(self._pf._h, self._ptr, what, b, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class ParticleFilter:
+    """A model + data set bound to one GPU (``get_private_model``, src/DiscretePOMP.jl:96-99)."""
+
+    def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], device: int = 0, rs_type: int = 1,
+                 essc: float = C_DF_ESS_CRIT, force_generic: bool = False):
+        self._lib = _abi.load_library()
+        self._h = C.c_void_p()
+        self.model = model
+        self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic)
+        self.n_states, self.n_params, self.n_obs = self.desc.n_states, self.desc.n_params, self.desc.n_obs
+        self.essc = essc  # accepted and unused, as in the reference (src/hmm_particle_filter.jl:63-68)
+        rc = self._lib.dpomp_create(self.desc.byref(), int(device), C.byref(self._h))
+        if rc != _abi.OK:
+            self._h = C.c_void_p()
+            raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
+        self.rs_type = rs_type
+        self._check(self._lib.dpomp_set_resampler(self._h, int(rs_type)))
+        self.last_status: Optional[np.ndarray] = None
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != _abi.OK:
+            raise DpompError(rc, self._lib.dpomp_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.dpomp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, raw_stream: Optional[int]):
+        """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
+        self._check(self._lib.dpomp_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def _theta_matrix(self, theta) -> np.ndarray:
+        th = np.asarray(theta, dtype=np.float64)
+        if th.ndim == 1:
+            th = th[:, None]
+        if th.shape[0] != self.n_params:
+            raise ValueError(f"theta must be a length-{self.n_params} vector or a {self.n_params} x B matrix (column per filter)")
+        return np.ascontiguousarray(th.T)  # [B][K] == column-major K x B
+
+    # -- the operator -------------------------------------------------------------------
+    def loglik(self, theta, np_particles: int = C_DF_PF_P, seed: int = 1, seg_base: int = 0) -> np.ndarray:
+        """``estimate_likelihood`` for every column of ``theta`` (K x B): B independent filters of
+        ``np_particles`` particles over all observations."""
+        th = self._theta_matrix(theta)
+        B = th.shape[0]
+        out = np.empty(B, dtype=np.float64)
+        status = np.zeros(B, dtype=np.uint32)
+        self._check(self._lib.dpomp_pf_loglik(self._h, _dptr(th), B, int(np_particles), int(seed) & (2**64 - 1),
+                                              int(seg_base), _dptr(out), status.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.last_status = status
+        return out
+
+    def alloc_population(self, B: int, np_particles: int) -> Population:
+        return Population(self, B, np_particles)
+
+    def partial_log_likelihood(self, pop: Population, theta, ymin: int, ymax: int, seed: int = 1,
+                               seg_base: int = 0) -> np.ndarray:
+        """``partial_log_likelihood!(pop, model, theta, fn_rs, essc, ymin, ymax)`` for every segment of
+        ``pop`` (1-based ``ymin``/``ymax`` as in the reference)."""
+        th = self._theta_matrix(theta)
+        if th.shape[0] != pop.B:
+            raise ValueError("one theta column per population segment")
+        out = np.empty(pop.B, dtype=np.float64)
+        status = np.zeros(pop.B, dtype=np.uint32)
+        self._check(self._lib.dpomp_pf_partial(self._h, pop._ptr, _dptr(th), int(ymin), int(ymax),
+                                               int(seed) & (2**64 - 1), int(seg_base), _dptr(out),
+                                               status.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.last_status = status
+        return out
+
+    def simulate(self, theta, n_sims: int = 1, seed: int = 1, seg_base: int = 0) -> np.ndarray:
+        """States of ``n_sims`` forward simulations per theta column at every observation time:
+        array [B, T, S, n_sims]."""
+        th = self._theta_matrix(theta)
+        B = th.shape[0]
+        out = np.empty((B, self.n_obs, self.n_states, int(n_sims)), dtype=np.int64)
+        self._check(self._lib.dpomp_simulate(self._h, _dptr(th), B, int(n_sims), int(seed) & (2**64 - 1), int(seg_base),
+                                             out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    # -- inspection ---------------------------------------------------------------------
+    def last_event_count(self) -> int:
+        ev = C.c_uint64()
+        self._check(self._lib.dpomp_last_event_count(self._h, C.byref(ev)))
+        return int(ev.value)
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.dpomp_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_stats(self) -> dict:
+        out = {}
+        for kid in range(self._lib.dpomp_kernel_count()):
+            n, ms = C.c_int64(), C.c_double()
+            self._check(self._lib.dpomp_get_kernel_stat(self._h, kid, C.byref(n), C.byref(ms)))
+            out[self._lib.dpomp_kernel_name(kid).decode()] = (int(n.value), float(ms.value))
+        return out
+
+    def selftest_numerics(self, x: np.ndarray, seed: int = 1):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = x.shape[0]
+        u, lg, ex = np.empty(n), np.empty(n), np.empty(n)
+        self._check(self._lib.dpomp_selftest_numerics(self._h, n, int(seed), _dptr(x), _dptr(u), _dptr(lg), _dptr(ex)))
+        return u, lg, ex
+
+
+def get_particle_filter_lpdf(model: DPOMPModel, obs_data: Sequence[Observation], np: int = C_DF_PF_P,
+                             rs_type: int = 1, essc: float = C_DF_ESS_CRIT, seed: int = 1, device: int = 0):
+    """Generate a SMC log-likelihood estimating function for ``model`` -- a.k.a. a particle filter
+    (src/hmm_utils.jl:281-284, src/hmm_particle_filter.jl:87-101).
+
+    Returns ``comp_log_pdf(parameters) -> float``.  The reference advances Julia's global RNG on
+    every call; here call ``n`` of the closure uses the stream ``(seed, n)``, or pass
+    ``comp_log_pdf(parameters, seed=...)`` to pin it.
+    """
+    pf = ParticleFilter(model, obs_data, device=device, rs_type=rs_type, essc=essc)
+    n_particles = int(np)
+    state = {"calls": 0}
+
+    def comp_log_pdf(parameters, seed: Optional[int] = None) -> float:
+        if seed is None:
+            s = (int(comp_log_pdf.base_seed) * 0x9E3779B97F4A7C15 + state["calls"]) & (2**64 - 1)
+            state["calls"] += 1
+        else:
+            s = int(seed)
+        return float(pf.loglik(parameters, n_particles, seed=s)[0])
+
+    comp_log_pdf.base_seed = seed
+    comp_log_pdf.filter = pf
+    return comp_log_pdf

@@ -1,0 +1,204 @@
+/*
+ * dpomp.h -- C ABI of the MI355X-native bootstrap particle filter for
+ * discrete-state POMP models (drop-in for the DiscretePOMP.jl particle-filter
+ * hot path).
+ *
+ * The reference has no FFI of its own; the entry points below are what a
+ * Julia `ccall` binding for the path would bind.  Each one names the reference
+ * interface it replaces (paths relative to the reference tree):
+ *
+ *   dpomp_create         <- get_private_model              src/DiscretePOMP.jl:96-99
+ *                           (DPOMPModel src/hmm_structs.jl:107-116 + Observation[] :30-35
+ *                            -> HiddenMarkovModel :119-130)
+ *   dpomp_pf_loglik      <- estimate_likelihood            src/hmm_particle_filter.jl:79-84
+ *                           and the closure comp_log_pdf   src/hmm_particle_filter.jl:97-99
+ *                           (public face get_particle_filter_lpdf src/hmm_utils.jl:281-284)
+ *   dpomp_pop_alloc      <- pop = zeros(Int64, P, S)       src/hmm_particle_filter.jl:82,
+ *                           per-theta populations          src/hmm_ibis.jl:26-30
+ *   dpomp_pf_partial     <- partial_log_likelihood!        src/hmm_particle_filter.jl:39-76
+ *   dpomp_pop_gather     <- theta-level ancestor copy      src/hmm_ibis.jl:71-75
+ *   dpomp_pop_download   <- reading the caller-owned `pop::Array{Int64,2}` after the call
+ *   dpomp_pop_upload     <- writing it before the call
+ *   dpomp_simulate       <- gillespie_sim (final states at each observation time only)
+ *                           src/hmm_sim.jl:86-102, iterate_particle! :55-70
+ *
+ * Conventions
+ *   - every function returns 0 (DPOMP_OK) or a negative DPOMP_E* code; the text of
+ *     the last error is available from dpomp_last_error(h) (or
+ *     dpomp_last_global_error() when no handle exists yet).  Nothing throws across
+ *     the boundary.
+ *   - `-inf` in an output log-likelihood is a RESULT (all weights zero), not an error.
+ *   - host arrays are caller-owned and only touched during the call; device buffers
+ *     are library-owned behind the opaque handles.
+ *   - calls block until the result is on the host.  A handle is bound to one device
+ *     and is not thread-safe; distinct handles are independent.
+ *   - matrices crossing the boundary use the reference's (Julia, column-major)
+ *     layouts: theta is K x B (theta[k + K*b]), populations are P x S
+ *     (pop[p + P*s]), m_transition is E x S given row-by-row in `transition[e][s]`.
+ *   - indices that the reference holds 1-based (t0_index, ymin, ymax) stay 1-based
+ *     here so a Julia caller passes them through unchanged.
+ *   - randomness is explicit and counter-based: every draw is a pure function of
+ *     (seed, global segment index, particle index, observation index, draw number),
+ *     so results do not depend on call order, batch composition or how segments are
+ *     sharded across GPUs.  See DESIGN.md "Numerical spec".
+ */
+#ifndef DPOMP_H
+#define DPOMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPOMP_ABI_VERSION 1
+
+#define DPOMP_MAX_STATES 8   /* S: state components        */
+#define DPOMP_MAX_EVENTS 8   /* E: event types             */
+#define DPOMP_MAX_PARAMS 8   /* K: model parameters        */
+#define DPOMP_MAX_FACTORS 2  /* integer factors per rate   */
+
+/* error codes */
+#define DPOMP_OK 0
+#define DPOMP_EINVAL (-1)   /* bad argument / descriptor              */
+#define DPOMP_EDEVICE (-2)  /* HIP runtime error                      */
+#define DPOMP_ENOMEM (-3)   /* host or device allocation failed       */
+#define DPOMP_ESTATE (-4)   /* call sequence error (e.g. ymin > 1 on a fresh population) */
+
+/* per-segment status bits returned next to the log-likelihood */
+#define DPOMP_ST_EVENT_CAP 1u   /* some particle hit max_events_per_interval (its weight was zeroed) */
+#define DPOMP_ST_ZERO_WEIGHT 2u /* all weights were zero at some observation: result is -inf */
+
+/* rate-term evaluation forms (association order follows the reference's Julia expressions) */
+#define DPOMP_RATE_LEFT 0  /* ((theta * f0) * f1) / d   e.g. hmm_examples.jl:108,:131,:152 */
+#define DPOMP_RATE_RATIO 1 /* theta * ((f0 * f1) / d), product in integers  e.g. hmm_examples.jl:165-166 */
+
+/* observation models */
+#define DPOMP_OBS_GAUSSIAN 1 /* partial_gaussian_obs_model hmm_examples.jl:59-67 */
+
+/* resamplers (rs_type of get_particle_filter_lpdf, hmm_utils.jl:281) */
+#define DPOMP_RS_SYSTEMATIC 1 /* rsp_systematic hmm_pf_resample.jl:24-42 (the reference's only working one) */
+#define DPOMP_RS_STRATIFIED 2 /* rsp_stratified :46-63 (throws in the reference; Kitagawa 1996 as documented) */
+#define DPOMP_RS_MULTINOMIAL 3 /* rsp_multinomial :5-20 (throws in the reference; inverse-CDF as documented) */
+
+/* built-in (compile-time specialised) rate evaluators; 0 = interpret `rate[]` on device */
+#define DPOMP_BUILTIN_GENERIC 0
+#define DPOMP_BUILTIN_SI 1       /* si_rf        hmm_examples.jl:103-105 */
+#define DPOMP_BUILTIN_SIR 2      /* sir_rf       :107-110 (SIR and SIS)  */
+#define DPOMP_BUILTIN_SEI 3      /* sei_rf       :112-115                */
+#define DPOMP_BUILTIN_SEIR 4     /* seir_rf      :117-121 (SEIR, SEIS)   */
+#define DPOMP_BUILTIN_SI_FD 5    /* si_rf_fd     :126-128                */
+#define DPOMP_BUILTIN_SIR_FD 6   /* sir_rf_fd    :130-133                */
+#define DPOMP_BUILTIN_SEI_FD 7   /* sei_rf_fd    :135-138                */
+#define DPOMP_BUILTIN_SEIR_FD 8  /* seir_rf_fd   :140-144                */
+#define DPOMP_BUILTIN_LOTKA 9    /* lotka_rf     :149-154                */
+#define DPOMP_BUILTIN_ROSSMAC 10 /* rossmac_rf   :159-168                */
+
+/* One event rate:  see DPOMP_RATE_*.  f_i = sum of the state components whose bit is
+ * set in factor_mask[i] (computed in integers, then promoted to double as Julia does);
+ * d likewise from denom_mask (0 = no division). */
+typedef struct dpomp_rate_term {
+    int32_t theta_index;  /* 0-based index into theta */
+    int32_t form;         /* DPOMP_RATE_* */
+    int32_t n_factors;    /* 0..DPOMP_MAX_FACTORS */
+    uint32_t factor_mask[DPOMP_MAX_FACTORS];
+    uint32_t denom_mask;
+} dpomp_rate_term;
+
+/* partial_gaussian_obs_model(sigma; seq, y_seq): log N(sum(y.val[y_seq]) | sum(pop[seq]), sigma) */
+typedef struct dpomp_obs_model {
+    int32_t kind;         /* DPOMP_OBS_GAUSSIAN */
+    uint32_t state_mask;  /* `seq`   : bit i = state component i (0-based) */
+    uint32_t value_mask;  /* `y_seq` : bit i = column i of Observation.val */
+    int32_t reserved;
+    double sigma;
+} dpomp_obs_model;
+
+/* Flattened DPOMPModel + Observation[] (hmm_structs.jl:107-116, :30-35). */
+typedef struct dpomp_model_desc {
+    int32_t abi_version;  /* DPOMP_ABI_VERSION */
+    int32_t n_states;     /* S = length(initial_condition) */
+    int32_t n_events;     /* E = size(m_transition, 1)     */
+    int32_t n_params;     /* K = length(theta)             */
+    int32_t builtin_id;   /* DPOMP_BUILTIN_*; the generic `rate[]` must be filled in either way */
+    int32_t t0_index;     /* as DPOMPModel.t0_index: 0 = start at t=0, i>0 = theta[i] (1-based) */
+    int64_t initial_condition[DPOMP_MAX_STATES];
+    int32_t transition[DPOMP_MAX_EVENTS][DPOMP_MAX_STATES]; /* m_transition[e][s] */
+    dpomp_rate_term rate[DPOMP_MAX_EVENTS];
+    dpomp_obs_model obs;
+    int32_t n_obs;        /* T = length(obs_data) */
+    int32_t n_obs_values; /* V = length(Observation.val) (same for every observation) */
+    const double* obs_time;   /* [T] Observation.time, non-decreasing */
+    const int64_t* obs_id;    /* [T] Observation.obs_id (<1: propagate only, no weight/resample) */
+    const int64_t* obs_value; /* [T*V] Observation.val, observation-major: obs_value[t*V + v] */
+    int64_t max_events_per_interval; /* per particle and interval; <=0 selects the default (1<<22).
+                                        The reference PF has no cap (hmm_particle_filter.jl:19-27). */
+} dpomp_model_desc;
+
+typedef struct dpomp_handle dpomp_handle;
+typedef struct dpomp_pop dpomp_pop;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+int dpomp_device_count(void);
+const char* dpomp_version(void);
+const char* dpomp_last_global_error(void);
+
+int dpomp_create(const dpomp_model_desc* desc, int device, dpomp_handle** out);
+void dpomp_destroy(dpomp_handle* h);
+const char* dpomp_last_error(const dpomp_handle* h);
+/* Run the kernels on an existing HIP stream (hipStream_t passed as void*); NULL = the
+ * handle's own stream. */
+int dpomp_set_stream(dpomp_handle* h, void* hip_stream);
+/* rs_type as in get_particle_filter_lpdf (DPOMP_RS_*; default systematic). */
+int dpomp_set_resampler(dpomp_handle* h, int rs_type);
+
+/* ---- the particle filter ------------------------------------------------------- */
+/* Full filter over observations 1..T for B independent parameter vectors
+ * (estimate_likelihood for each theta[:,b]).  out_ll[B]; out_status[B] may be NULL. */
+int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
+                    int64_t seg_base, double* out_ll, uint32_t* out_status);
+
+/* Device-resident populations for the incremental form. */
+int dpomp_pop_alloc(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out);
+void dpomp_pop_free(dpomp_handle* h, dpomp_pop* pop);
+
+/* partial_log_likelihood!(pop, model, theta, fn_rs, essc, ymin, ymax) for every segment.
+ * ymin == 1 re-initialises the populations; ymin > 1 resumes from obs_time[ymin-1]
+ * (1-based, as the reference).  Returns the sum over ymin..ymax of log mean weight. */
+int dpomp_pf_partial(dpomp_handle* h, dpomp_pop* pop, const double* theta, int32_t ymin,
+                     int32_t ymax, uint64_t seed, int64_t seg_base, double* out_ll,
+                     uint32_t* out_status);
+
+/* pop[b] <- pop[ancestors[b]] for all b (0-based ancestors), as hmm_ibis.jl:71-75. */
+int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* pop, const int64_t* ancestors);
+/* Segment b as a P x S column-major Int64 matrix. */
+int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* pop, int64_t b, int64_t* out);
+int dpomp_pop_upload(dpomp_handle* h, dpomp_pop* pop, int64_t b, const int64_t* in);
+
+/* Forward simulation of B*P independent trajectories from the initial condition,
+ * recording the state at each observation time: out[((b*T + t)*S + s)*P + p]. */
+int dpomp_simulate(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
+                   int64_t seg_base, int64_t* out);
+
+/* ---- inspection (parity tests, bench) ----------------------------------------- */
+#define DPOMP_DBG_LOGW 1          /* double[P]  log-weights of the last weighted observation */
+#define DPOMP_DBG_OFFSPRING_END 2 /* int32[P]   N_j of the last resampling       */
+int dpomp_debug_download(dpomp_handle* h, const dpomp_pop* pop, int what, int64_t b, void* out);
+
+/* Device evaluation of the shared numerics for n inputs: uniforms of particle-stream
+ * (seed, seg, p, k), dlog(x), dexp(-x).  Arrays may be NULL. */
+int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const double* x_in,
+                            double* out_uniform, double* out_log, double* out_exp);
+
+/* Per-kernel HIP-event timing, accumulated while profiling is on. */
+int dpomp_set_profiling(dpomp_handle* h, int on);
+int dpomp_kernel_count(void);
+const char* dpomp_kernel_name(int kernel_id);
+int dpomp_get_kernel_stat(dpomp_handle* h, int kernel_id, int64_t* launches, double* total_ms);
+/* Gillespie events executed by the last pf call (sum over all particles). */
+int dpomp_last_event_count(dpomp_handle* h, uint64_t* events);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPOMP_H */

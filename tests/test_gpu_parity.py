@@ -1,0 +1,244 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle's SPEC mode.
+
+Bar: integer work (states, offspring boundaries, event counts) bit-exact; the log-likelihood,
+being a fixed sequence of IEEE operations on both sides, is also compared for equality, with a
+1e-12 absolute tolerance stated as the fallback contract.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import exact_sis
+
+pytestmark = pytest.mark.gpu
+
+LL_TOL = 1e-12
+
+
+def _assert_ll(got, ref):
+    if math.isinf(ref):
+        assert got == ref
+    else:
+        assert abs(got - ref) <= LL_TOL, (got, ref)
+
+
+@pytest.fixture(scope="module")
+def sis(dp, pooley):
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    yield pf
+    pf.close()
+
+
+def test_device_numerics_match_oracle_bitwise(sis, orc):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(4096), 1.0 - rng.random(512) * 1e-6, rng.random(512) * 1e-12, [2.0 ** -53, 1 - 2.0 ** -53]])
+    u, lg, ex = sis.selftest_numerics(x, seed=77)
+    ref_u = np.array([orc.uniforms(77, 0, i, 0, orc.DOMAIN_PROPAGATE, 1)[0] for i in range(len(x))])
+    assert np.array_equal(u, ref_u)
+    assert np.array_equal(lg, orc.dlog(x))
+    assert np.array_equal(ex, orc.dexp(-37.0 * x))
+
+
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097])
+def test_sis_full_filter_matches_oracle(sis, orc, P):
+    theta = [0.003, 0.1]
+    pop = sis.alloc_population(1, P)
+    ll = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=11)
+    ref = orc.pf_loglik(sis.desc, P, theta, seed=11)
+    assert np.array_equal(pop.download(0), ref.pop)
+    assert sis.last_event_count() == ref.events
+    assert sis.last_status[0] == ref.status
+    _assert_ll(ll[0], ref.ll)
+    assert ll[0] == ref.ll  # in practice exact
+
+
+def test_step_by_step_states_logw_and_offspring(sis, orc, dp):
+    """Observation by observation: propagated-and-resampled states, log-weights and offspring
+    boundaries all equal the oracle's."""
+    P, theta, seed = 3000, [0.0032, 0.09], 5
+    pop = sis.alloc_population(1, P)
+    ref_pop = np.zeros((P, 2), dtype=np.int64)
+    for k in range(1, sis.n_obs + 1):
+        ll = sis.partial_log_likelihood(pop, theta, k, k, seed=seed)
+        r = orc.pf_partial(sis.desc, ref_pop, theta, k, k, seed=seed, trace=True)
+        assert np.array_equal(pop.download(0), ref_pop), f"states differ after observation {k}"
+        assert np.array_equal(pop.debug(dp.DBG_LOGW), r.logw)
+        if k < sis.n_obs:
+            assert np.array_equal(pop.debug(dp.DBG_OFFSPRING_END).astype(np.int64), r.offspring_end)
+        assert ll[0] == r.ll
+
+
+def test_incremental_equals_full(sis):
+    P, theta = 2048, [0.003, 0.1]
+    pop = sis.alloc_population(1, P)
+    full = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=3)[0]
+    final = pop.download(0).copy()
+    parts = [sis.partial_log_likelihood(pop, theta, k, k, seed=3)[0] for k in range(1, sis.n_obs + 1)]
+    assert np.array_equal(pop.download(0), final)
+    assert abs(sum(parts) - full) < 1e-12
+
+
+def test_batched_segments_are_independent_and_partition_invariant(sis, orc):
+    """B filters in one launch == B single launches with seg_base: the RNG is keyed by the global
+    segment index, so sharding segments over GPUs cannot change a result."""
+    P = 1500
+    thetas = np.array([[0.003, 0.0025, 0.004, 0.0032], [0.1, 0.08, 0.15, 0.1]])
+    batch = sis.loglik(thetas, P, seed=9, seg_base=10)
+    for b in range(4):
+        single = sis.loglik(thetas[:, b], P, seed=9, seg_base=10 + b)[0]
+        ref = orc.pf_loglik(sis.desc, P, thetas[:, b], seed=9, seg=10 + b).ll
+        assert batch[b] == single == ref
+
+
+def test_determinism_same_seed_same_bits(sis):
+    a = sis.loglik([0.003, 0.1], 10000, seed=123)
+    b = sis.loglik([0.003, 0.1], 10000, seed=123)
+    c = sis.loglik([0.003, 0.1], 10000, seed=124)
+    assert a[0] == b[0] and a[0] != c[0]
+
+
+CASES = [
+    ("SI", [100, 1], False, [0.003]),
+    ("SI", [100, 1], True, [0.3]),
+    ("SIR", [100, 1, 0], False, [0.003, 0.1]),
+    ("SIR", [100, 1, 0], True, [0.3, 0.1]),
+    ("SIS", [100, 1], True, [0.3, 0.1]),
+    ("SEI", [100, 0, 1], False, [0.005, 0.2]),
+    ("SEI", [100, 0, 1], True, [0.5, 0.2]),
+    ("SEIR", [100, 0, 1, 0], False, [0.005, 0.2, 0.1]),
+    ("SEIR", [100, 0, 1, 0], True, [0.5, 0.2, 0.1]),
+    ("SEIS", [100, 0, 1], False, [0.005, 0.2, 0.1]),
+    ("SEIS", [100, 0, 1], True, [0.5, 0.2, 0.1]),
+    ("LOTKA", [70, 70], False, [0.5, 0.0025, 0.3]),
+    ("ROSSMAC", [100, 10, 200, 20], False, [0.02, 0.05, 0.04, 0.1]),
+]
+
+
+def _synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99):
+    """Observations simulated with the ORACLE's forward simulator (the default flow of the
+    reference: gillespie_sim with dmy_obs_fn, y.val = state)."""
+    times = [tmax * (i + 1) / T for i in range(T)]
+    blank = [dp.Observation(t, 1, 1.0, [0] * model.n_states) for t in times]
+    d = dp.ModelDescriptor(model, blank)
+    traj = orc.simulate(d, 1, theta, seed=seed)  # [T][S][1]
+    return [dp.Observation(t, 1, 1.0, [int(v) for v in traj[i, :, 0]]) for i, t in enumerate(times)]
+
+
+@pytest.mark.parametrize("name,x0,fd,theta", CASES)
+@pytest.mark.parametrize("generic", [False, True])
+def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic):
+    """Every catalogue model, compiled built-in evaluator and table-driven generic evaluator,
+    equals the oracle (which only knows the generic table)."""
+    model = dp.generate_model(name, x0, freq_dep=fd)
+    y = _synthetic_data(dp, orc, model, theta)
+    pf = dp.ParticleFilter(model, y, force_generic=generic)
+    P = 777
+    pop = pf.alloc_population(1, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, len(y), seed=42)
+    ref = orc.pf_loglik(pf.desc, P, theta, seed=42)
+    assert np.array_equal(pop.download(0), ref.pop)
+    assert pf.last_event_count() == ref.events
+    assert ll[0] == ref.ll
+    pf.close()
+
+
+def test_custom_model_with_t0_index_and_unweighted_observation(dp, orc, make_obs):
+    """A hand-built model (the reference's custom_sim testset, test/runtests.jl:74-100, extended with
+    an unknown initial time and an obs_id = 0 row that must neither weight nor resample)."""
+    rf = dp.RateFunction([dp.RateTerm(1, ((1,), (2,))), dp.RateTerm(2, ((2,),))])
+    model = dp.generate_custom_model("SIS", rf, [100, 1], [[-1, 1], [1, -1]], t0_index=3)
+    y = make_obs([20.0, 30.0, 40.0, 60.0], [[0, 18], [0, 0], [0, 65], [0, 70]], obs_ids=[1, 0, 1, 1])
+    pf = dp.ParticleFilter(model, y)
+    theta = [0.003, 0.1, 4.5]
+    P = 2000
+    pop = pf.alloc_population(1, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, 4, seed=8)
+    ref = orc.pf_loglik(pf.desc, P, theta, seed=8, trace=True)
+    assert ref.per_obs_ll[1] == 0.0
+    assert np.array_equal(pop.download(0), ref.pop)
+    assert ll[0] == ref.ll
+    pf.close()
+
+
+def test_event_cap_flags_and_zeroes_the_weight(dp, orc, pooley):
+    model = dp.generate_model("SIS", [100, 1])
+    model.max_events_per_interval = 150  # intervals 2..5 need ~270 events per particle
+    pf = dp.ParticleFilter(model, pooley)
+    ll = pf.loglik([0.003, 0.1], 512, seed=2)
+    ref = orc.pf_loglik(pf.desc, 512, [0.003, 0.1], seed=2)
+    assert pf.last_status[0] & dp.ST_EVENT_CAP and ref.status & dp.ST_EVENT_CAP
+    assert (ll[0] == ref.ll) or (math.isinf(ll[0]) and math.isinf(ref.ll))
+    assert pf.last_event_count() == ref.events
+    pf.close()
+
+
+def test_impossible_data_gives_minus_inf_not_an_error(dp, orc, make_obs):
+    model = dp.generate_model("SIS", [100, 1])
+    y = make_obs([20.0, 40.0], [[0, 5000], [0, 5000]])  # far outside the reachable states: exp underflows
+    pf = dp.ParticleFilter(model, y)
+    ll = pf.loglik([0.003, 0.1], 256, seed=1)
+    ref = orc.pf_loglik(pf.desc, 256, [0.003, 0.1], seed=1)
+    # max-shifted weights cannot underflow: the filter stays finite where the reference returns -Inf
+    assert ll[0] == ref.ll and math.isfinite(ll[0])
+    pf.close()
+
+
+def test_population_gather_upload_download(sis):
+    P = 1024
+    pop = sis.alloc_population(3, P)
+    thetas = np.array([[0.003, 0.0025, 0.004], [0.1, 0.08, 0.15]])
+    sis.partial_log_likelihood(pop, thetas, 1, 2, seed=4)
+    before = [pop.download(b).copy() for b in range(3)]
+    pop.gather([2, 0, 0])
+    assert np.array_equal(pop.download(0), before[2])
+    assert np.array_equal(pop.download(1), before[0])
+    assert np.array_equal(pop.download(2), before[0])
+    pop.upload(1, before[1])
+    assert np.array_equal(pop.download(1), before[1])
+
+
+def test_call_sequence_errors(dp, sis):
+    pop = sis.alloc_population(1, 64)
+    with pytest.raises(dp.DpompError):
+        sis.partial_log_likelihood(pop, [0.003, 0.1], 2, 3)  # never initialised
+    with pytest.raises(dp.DpompError):
+        sis.partial_log_likelihood(pop, [0.003, 0.1], 0, 3)
+    with pytest.raises(ValueError):
+        sis.loglik([0.003], 64)
+
+
+def test_simulate_matches_oracle(dp, orc, pooley):
+    model = dp.generate_model("SEIR", [100, 0, 1, 0])
+    blank = [dp.Observation(t, 1, 1.0, [0, 0, 0, 0]) for t in (20.0, 40.0, 60.0, 80.0, 100.0)]
+    pf = dp.ParticleFilter(model, blank)
+    theta = [0.005, 0.2, 0.1]
+    got = pf.simulate(theta, n_sims=300, seed=6)
+    ref = orc.simulate(pf.desc, 300, theta, seed=6)
+    assert np.array_equal(got[0], ref)
+    pf.close()
+
+
+# ---- full size (BASELINE config 2): properties that do not need the oracle at 2^20 ---------------
+def test_full_size_pooley_2pow20(sis, dp):
+    P = 1 << 20
+    theta = [0.003, 0.1]
+    pop = sis.alloc_population(1, P)
+    lls = []
+    for k in range(1, sis.n_obs + 1):
+        lls.append(sis.partial_log_likelihood(pop, theta, k, k, seed=2026)[0])
+        if k < sis.n_obs:
+            N = pop.debug(dp.DBG_OFFSPRING_END).astype(np.int64)
+            assert N[-1] == P and np.all(np.diff(N) >= 0) and N[0] >= 0  # counts sum to P, ancestors sorted
+            states = pop.download(0)
+            assert np.all(states.sum(axis=1) == 101)  # closed population: S + I conserved
+    exact, incs = exact_sis.exact_sis_loglik(theta, [100, 1], exact_sis.POOLEY_TIMES, exact_sis.POOLEY_CASES)
+    # Monte-Carlo tolerance: at P = 2^20 the per-observation sd is ~4e-3/sqrt(P/1024) ~ 1e-3 (sd of ll at
+    # P = 1024 is 0.12 over 5 observations); 0.02 is > 5 sd of the total.
+    assert abs(sum(lls) - exact) < 0.02, (sum(lls), exact)
+    for got, want in zip(lls, incs):
+        assert abs(got - want) < 0.02
+    # the same call twice gives the same bits; one call over 1..T equals the increments
+    full = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=2026)[0]
+    assert abs(full - sum(lls)) < 1e-12
