@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the particle-filter hot path (BASELINE.json metric: particle-steps/sec on
+Pooley SIS at 2^20 particles, plus log-ML error against the CPU reference path).
+
+One "step" = one full bootstrap particle filter call over the T = 5 Pooley observations with
+P = 2^20 particles per GPU (propagate -> weight -> log-mean-weight -> systematic resample, x5).
+N GPUs run N independent filters (one per rank, weak scaling) and all-gather their log-ML
+estimates over RCCL after every step -- the sharding BASELINE.json's north star prescribes for
+independent pMCMC chains / theta-particles.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+POOLEY = [(20.0, [0, 18]), (40.0, [0, 65]), (60.0, [0, 70]), (80.0, [0, 66]), (100.0, [0, 67])]  # data/pooley.csv
+THETA = [0.003, 0.1]
+EXACT_LL = -15.6873794556  # exact CTMC forward algorithm (oracle/exact_sis.py)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(P, S):
+    """bytes per particle-step with Int64 state as in the reference (w = 8)."""
+    return {
+        "k_propagate": (2 * S + 1) * 8 * P,   # read state, write state, write log-weight
+        "k_wsum": 8 * P,                      # normalise: read weight
+        "k_scan_blocks": 0,
+        "k_offsets": 16 * P,                  # scan: read 8 + write 8
+        "k_gather": (2 * S + 1) * 8 * P,      # resample: read cum. weight + gather state + write state
+    }
+
+
+def cpu_baseline(dp, P_serial, P_parallel):
+    """The oracle (C restatement of the reference algorithm) timed on this host: serial, as the
+    reference runs, and with all host cores (OpenMP over particles)."""
+    from oracle import oracle as orc
+    y = [dp.Observation(t, 1, 1.0, v) for t, v in POOLEY]
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), y)
+    T = len(y)
+    t0 = time.perf_counter()
+    r1 = orc.pf_loglik(desc, P_serial, THETA, seed=1, nthreads=1)
+    t_serial = time.perf_counter() - t0
+    cores = max(1, min(os.cpu_count() or 1, orc.max_threads()))
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    orc.pf_loglik(desc, 4096, THETA, seed=2, nthreads=cores)  # spin the thread pool up
+    t0 = time.perf_counter()
+    rp = orc.pf_loglik(desc, P_parallel, THETA, seed=1, nthreads=cores)
+    t_par = time.perf_counter() - t0
+    return {
+        "value": P_parallel * T / t_par,
+        "unit": "particle-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle C restatement (reference is Julia, absent here); full Pooley SIS PF, "
+                  f"{P_parallel} particles on {cores} OpenMP threads ({t_par:.2f} s); serial run "
+                  f"{P_serial} particles ({t_serial:.2f} s)",
+        "serial_value": P_serial * T / t_serial,
+        "serial_events_per_s": r1.events / t_serial,
+        "events_per_s": rp.events / t_par,
+        "julia_on_path": bool(any(os.access(os.path.join(p, "julia"), os.X_OK) for p in os.environ.get("PATH", "").split(os.pathsep))),
+        "note": "the restatement does not heap-allocate per event as the Julia code does "
+                "(src/hmm_examples.jl:12-14): it is faster than the real reference, so GPU/CPU ratios are conservative",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=1 << 20)
+    ap.add_argument("--cpu-serial-particles", type=int, default=1 << 16)
+    ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 19)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the particle filter has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import dpomp_amd as dp
+
+    y = [dp.Observation(t, 1, 1.0, v) for t, v in POOLEY]
+    model = dp.generate_model("SIS", [100, 1])
+    pf = dp.ParticleFilter(model, y, device=local_rank)
+    stream = torch.cuda.current_stream()
+    pf.set_stream(stream.cuda_stream)
+    P, T, S = args.particles, len(y), model.n_states
+    gathered = torch.zeros(world, dtype=torch.float64, device="cuda")
+    mine = torch.zeros(1, dtype=torch.float64, device="cuda")
+
+    def step(i):
+        ll = pf.loglik(THETA, P, seed=1000 + i, seg_base=rank)
+        if dist is not None:  # the only collective of the path: log-ML estimates of the independent filters
+            mine[0] = float(ll[0])
+            dist.all_gather_into_tensor(gathered, mine)
+            return gathered
+        return ll
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    pf.set_profiling(True)  # HIP events around every kernel, on the launch stream
+    lls, events = [], 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+        lls.append(float(out[rank]) if dist is not None else float(out[0]))
+        events += pf.last_event_count()
+    fence()
+    elapsed = time.perf_counter() - t0
+    pf.set_profiling(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        ev = torch.tensor([float(events)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(ev)
+        events = float(ev[0])
+
+    if rank == 0:
+        stats = pf.kernel_stats()
+        alg = algorithmic_bytes(P, S)
+        kernels = {}
+        for name, (n, ms) in stats.items():
+            if n == 0:
+                continue
+            avg_us = ms / n * 1e3
+            k = {"launches": n, "avg_us": round(avg_us, 2)}
+            if alg.get(name):
+                k["algorithmic_bytes"] = alg[name]
+                k["achieved_GBs"] = round(alg[name] / (avg_us * 1e-6) / 1e9, 1)
+            kernels[name] = k
+        # dominant HBM-bound kernel of the path = the resampling gather (most bytes per launch)
+        g = kernels.get("k_gather", {})
+        roofline = {
+            "kernel": "k_gather",
+            "bound": "hbm",
+            "achieved": g.get("achieved_GBs"),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(g.get("achieved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
+            "traffic": None,
+            "note": "memory-bound stage (normalise+scan+resample); k_propagate, which holds >95% of the "
+                    "time, is FP64-VALU/divergence bound (SURVEY.md 8d) and is reported under 'propagate'",
+        }
+        mem_us = sum(kernels[k]["avg_us"] for k in ("k_wsum", "k_scan_blocks", "k_offsets", "k_gather") if k in kernels)
+        mem_bytes = alg["k_wsum"] + alg["k_offsets"] + alg["k_gather"]
+        roofline["stage_achieved_GBs"] = round(mem_bytes / (mem_us * 1e-6) / 1e9, 1) if mem_us else None
+        prop = kernels.get("k_propagate", {})
+        propagate = {
+            "avg_us": prop.get("avg_us"),
+            "events_per_s": round(events / world / args.steps / (prop.get("avg_us", 1) * T * 1e-6)) if prop else None,
+            "events_per_particle_per_call": round(events / world / args.steps / P, 1),
+            "hbm_achieved_GBs": prop.get("achieved_GBs"),
+            "bound": "fp64-valu + wave divergence (not HBM, not MFMA)",
+        }
+        mean_ll = float(np.mean(lls))
+        result = {
+            "metric": "particle-steps/sec",
+            "value": world * P * T * args.steps / elapsed,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "Pooley SIS data set of the reference (5 observations); synthetic in the sense of no dataset download",
+            "config": {"workload": "Pooley SIS, 2^20 particles, single bootstrap PF per GPU (propagate+weight+resample, T=5)",
+                       "particles_per_filter": P, "filters_per_gpu": 1, "observations": T, "theta": THETA,
+                       "parallelism": f"{world} independent filters, all-gather of log-ML" if world > 1 else "single filter"},
+            "events_per_s": events / elapsed,
+            "log_ml": {"mean": mean_ll, "exact": EXACT_LL, "abs_err_vs_exact": abs(mean_ll - EXACT_LL),
+                       "sd_over_steps": float(np.std(lls))},
+            "roofline": roofline,
+            "propagate": propagate,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            # log-ML abs error vs the CPU reference path at identical seed (bit parity expected)
+            Pc = 1 << 16
+            gpu_ll = float(pf.loglik(THETA, Pc, seed=7)[0])
+            cpu_ll = orc.pf_loglik(pf.desc, Pc, THETA, seed=7, nthreads=max(1, os.cpu_count() or 1)).ll
+            result["log_ml"]["abs_err_vs_cpu_same_seed"] = abs(gpu_ll - cpu_ll)
+            result["log_ml"]["same_seed_particles"] = Pc
+            result["cpu_baseline"] = cpu_baseline(dp, args.cpu_serial_particles, args.cpu_parallel_particles)
+            result["speedup_vs_cpu_allcores"] = result["value"] / result["cpu_baseline"]["value"]
+            result["speedup_vs_cpu_serial"] = result["value"] / result["cpu_baseline"]["serial_value"]
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

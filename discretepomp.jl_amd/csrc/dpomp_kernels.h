@@ -218,12 +218,13 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < a.P;
-    int32_t* st = a.state + (int64_t)b * S * a.Pp;
+    const int s_real = R::kGeneric ? a.m.S : S;  // RGeneric pads S up to 2/4/8: rows >= s_real do not exist
+    int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
 
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = valid ? st[(int64_t)s * a.Pp + p] : 0;
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
 
     double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     double g = -__builtin_inf();
     if (valid) {
 #pragma unroll
-        for (int s = 0; s < S; ++s) st[(int64_t)s * a.Pp + p] = x[s];
+        for (int s = 0; s < S; ++s)
+            if (s < s_real) st[(int64_t)s * a.Pp + p] = x[s];
         if (a.want_weight) {
             int xs = 0;
 #pragma unroll
@@ -403,13 +405,12 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
 
     const unsigned long long W = a.wtot[b];
-    const double Wd = u64_to_double(W);
     Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
     const double r = u01(stream_next(rs));  // rand() of hmm_pf_resample.jl:27
     int n[kItems];
 #pragma unroll
     for (int q = 0; q < kItems; ++q)
-        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], Wd, a.P, r);
+        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
     *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
 }

@@ -164,8 +164,11 @@ DPOMP_HD uint64_t fixed_weight(double g, double m, int sh) {
     return (uint64_t)__builtin_rint(dexp(x) * (double)((uint64_t)1 << sh));
 }
 
-// Offspring boundary N(c) = clamp(ceil(c/W P - r), 0, P): slots [N(c_{j-1}), N(c_j)) copy particle j.
-DPOMP_HD int64_t offspring_end(uint64_t c, double Wd, int64_t P, double r) {
+// Offspring boundary N(c) = clamp(ceil(c/W P - r), 0, P), N(W) = P: slots [N(c_{j-1}), N(c_j)) copy
+// particle j.  (c == W is pinned to P because P - r can round down to P - 1 for r within 2^-53 of 1.)
+DPOMP_HD int64_t offspring_end(uint64_t c, uint64_t W, int64_t P, double r) {
+    if (c >= W) return P;
+    const double Wd = u64_to_double(W);
     const double pos = (u64_to_double(c) / Wd) * (double)P - r;
     const double n = __builtin_ceil(pos);
     if (!(n > 0.0)) return 0;

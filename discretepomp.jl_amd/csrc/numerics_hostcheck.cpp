@@ -16,7 +16,7 @@ double hc_dlog(double x) { return dpomp::dlog(x); }
 double hc_dexp(double x) { return dpomp::dexp(x); }
 int hc_weight_shift(int64_t P) { return dpomp::weight_shift(P); }
 uint64_t hc_fixed_weight(double g, double m, int sh) { return dpomp::fixed_weight(g, m, sh); }
-int64_t hc_offspring_end(uint64_t c, double Wd, int64_t P, double r) { return dpomp::offspring_end(c, Wd, P, r); }
+int64_t hc_offspring_end(uint64_t c, uint64_t W, int64_t P, double r) { return dpomp::offspring_end(c, W, P, r); }
 double hc_log_mean_weight(double m, uint64_t W, int sh, int64_t P) { return dpomp::log_mean_weight(m, W, sh, P); }
 double hc_ordered_roundtrip(double d) { return dpomp::ordered_value(dpomp::ordered_key(d)); }
 uint64_t hc_ordered_key(double d) { return dpomp::ordered_key(d); }

@@ -330,9 +330,11 @@ uint64_t orc_fixed_weight(double g, double m, int sh) {
 
 /* SPEC offspring boundary: number of output slots i with ancestor <= j, given the inclusive
  * fixed-point cumulative weight c of particle j:  N = clamp(ceil(c/W * P - r), 0, P).
- * Monotone in c, N(0) = 0, N(W) = P.  Slot i takes the first j with N_j > i, i.e. the first j
+ * Monotone in c, N(0) = 0, N(W) = P (pinned).  Slot i takes the first j with N_j > i, i.e. the first j
  * with c_j > (i + r)/P * W  -- rsp_systematic's `while u[i] > cw[j]` (hmm_pf_resample.jl:36). */
-int64_t orc_offspring_end(uint64_t c, double Wd, int64_t P, double r) {
+int64_t orc_offspring_end(uint64_t c, uint64_t W, int64_t P, double r) {
+    if (c >= W) return P; /* N(W) = P exactly: P - r can round down to P - 1 when r is within 2^-53 of 1 */
+    double Wd = u64_to_double(W);
     double pos = (u64_to_double(c) / Wd) * (double)P - r;
     double n = ceil(pos);
     if (!(n > 0.0)) return 0;
@@ -389,7 +391,7 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
         if (d->obs_id[k] > 0) { /* :58 */
             if (tr && tr->logw) memcpy(tr->logw, logw, sizeof(double) * P);
             double inc;
-            double Wd = 0.0;
+            uint64_t W = 0;
             if (mode == ORC_MODE_FAITHFUL) {
                 double total_weight = 0.0; /* :13 */
                 for (int64_t p = 0; p < P; ++p) {
@@ -409,7 +411,8 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                 if (c == 0) {
                     inc = -INFINITY;
                 } else {
-                    Wd = u64_to_double(c);
+                    double Wd = u64_to_double(c);
+                    W = c;
                     inc = m + orc_dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
                 }
             }
@@ -439,8 +442,7 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                      * the reference degenerates to (u = 0, `0 > cw[1]` false). */
                     int64_t start = 0;
                     for (int64_t j = 0; j < P; ++j) {
-                        int64_t end = (Wd > 0.0) ? orc_offspring_end(cint[j], Wd, P, r)
-                                                 : P;
+                        int64_t end = (W > 0) ? orc_offspring_end(cint[j], W, P, r) : P;
                         if (tr && tr->offspring_end) tr->offspring_end[j] = end;
                         for (int64_t i = start; i < end; ++i) {
                             for (int s = 0; s < S; ++s) pop[i + P * s] = old_p[j + P * s];

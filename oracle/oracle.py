@@ -52,7 +52,7 @@ def lib():
         L.orc_fixed_weight.restype = C.c_uint64
         L.orc_fixed_weight.argtypes = [C.c_double, C.c_double, C.c_int]
         L.orc_offspring_end.restype = C.c_int64
-        L.orc_offspring_end.argtypes = [C.c_uint64, C.c_double, C.c_int64, C.c_double]
+        L.orc_offspring_end.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_double]
         L.orc_rates.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int64), dp]
         L.orc_choose_event.argtypes = [dp, C.c_int, C.c_double]
         L.orc_obs_loglik.restype = C.c_double
