@@ -222,6 +222,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
 
+    __shared__ double s_log[128][2];  // dlog table: one ds_read_b128 per event
+    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    __syncthreads();
+
     int x[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
             const double tot = cum[E - 1];
             if (tot == 0.0) break;
             const double u1 = u01(stream_next(rng));
-            time = time - dlog(u1) / tot;
+            time = time - dlog_tab(u1, s_log) / tot;
             if (time > tmax) break;
             const double etc = u01(stream_next(rng)) * tot;
             TW tw = (TW)a.m.trans_packed[e_real - 1];

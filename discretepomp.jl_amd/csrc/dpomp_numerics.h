@@ -10,11 +10,17 @@
 
 #if defined(__HIPCC__)
 #define DPOMP_HD __host__ __device__ __forceinline__
+#define DPOMP_D __device__ __forceinline__
+#define DPOMP_TABLE_QUAL static __device__ const
 #else
 #include <cmath>
 #include <cstring>
 #define DPOMP_HD static inline
+#define DPOMP_D static inline
+#define DPOMP_TABLE_QUAL static const
 #endif
+
+#include "dpomp_log_table.h"
 
 namespace dpomp {
 
@@ -97,36 +103,35 @@ DPOMP_HD double u01(uint64_t x) {
     return (d - 1.0) + 0x1p-53;
 }
 
-// log(x), positive normal x.  x = 2^k (1+f), sqrt(2)/2 <= 1+f < sqrt(2); s = f/(2+f);
-// log(1+f) = f - f^2/2 + s (f^2/2 + R(s^2)), R the degree-7 minimax of the fdlibm family.
-DPOMP_HD double dlog(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    const uint64_t bits = double_to_bits(x);
-    uint32_t hx = (uint32_t)(bits >> 32);
-    const uint32_t lx = (uint32_t)bits;
-    int32_t k = (int32_t)(hx >> 20) - 1023;
-    hx &= 0x000fffffu;
-    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
-    hx |= i ^ 0x3ff00000u;
-    k += (int32_t)(i >> 20);
-    const double m = bits_to_double(((uint64_t)hx << 32) | lx);
-    const double f = m - 1.0;
-    const double hfsq = 0.5 * f * f;
-    const double s = f / (2.0 + f);
-    const double z = s * s;
-    const double w = z * z;
-    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double dk = (double)k;
-    const double a = __builtin_fma(dk, ln2_lo, s * (hfsq + R));
-    const double b = (a - hfsq) + f;
-    return __builtin_fma(dk, ln2_hi, b);
+// log(x), positive normal x, table-driven and division-free (the structure of glibc's log):
+//   bits(x) - OFF splits x = 2^k z with z in [0.6875, 1.375); subinterval i = next 7 bits;
+//   T[i] = (invc, logc) with invc = RN(1/c_i), logc = RN(-log(invc))  (tools/gen_log_table.py);
+//   r = fma(z, invc, -1)  (|r| <= 2^-7),  log(x) = k ln2 + logc + log1p(r),
+//   log1p(r) = r + r^2 (A0 + A1 r + ... + A6 r^6),  A_n = (-1)^(n+1)/(n+2).
+// The two subintervals touching 1 have c = 1 (invc = 1, logc = 0), so log(x) keeps full relative
+// accuracy as x -> 1.  Max error 1 ulp (tests/test_oracle_numerics.py).  In k_propagate the
+// table lives in LDS (one ds_read_b128 per event).
+DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
+    const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    const double A0 = -0.5, A1 = 0x1.5555555555555p-2, A2 = -0.25, A3 = 0x1.999999999999ap-3,
+                 A4 = -0x1.5555555555555p-3, A5 = 0x1.2492492492492p-3, A6 = -0.125;
+    const uint64_t ix = double_to_bits(x);
+    const uint64_t tmp = ix - 0x3FE6000000000000ull;
+    const int i = (int)((uint32_t)(tmp >> 45) & 127u);
+    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const double z = bits_to_double(ix - (tmp & 0xFFF0000000000000ull));
+    const double invc = T[i][0], logc = T[i][1];
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = __builtin_fma(kd, Ln2hi, logc);
+    const double hi = w + r;
+    const double lo = __builtin_fma(kd, Ln2lo, (w - hi) + r);
+    const double r2 = r * r;
+    const double p = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r,
+                     __builtin_fma(r, __builtin_fma(r, A6, A5), A4), A3), A2), A1), A0);
+    return __builtin_fma(r2, p, lo) + hi;
 }
+DPOMP_D double dlog(double x) { return dlog_tab(x, kLogTable); }
 
 // exp(x), -37 <= x <= 0.
 DPOMP_HD double dexp(double x) {
@@ -178,7 +183,7 @@ DPOMP_HD int64_t offspring_end(uint64_t c, uint64_t W, int64_t P, double r) {
 
 // log mean weight of one observation: m + log((W 2^-sh) / P), i.e. log(cum_weight[end]/P)
 // of hmm_particle_filter.jl:60 with the max factored out.
-DPOMP_HD double log_mean_weight(double m, uint64_t W, int sh, int64_t P) {
+DPOMP_D double log_mean_weight(double m, uint64_t W, int sh, int64_t P) {
     const double Wd = u64_to_double(W);
     return m + dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
 }

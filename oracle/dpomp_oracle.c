@@ -40,6 +40,7 @@
 #endif
 
 #include "../include/dpomp.h"
+#include "orc_log_table.h"
 
 #define ORC_MODE_SPEC 0
 #define ORC_MODE_FAITHFUL 1
@@ -114,39 +115,31 @@ void orc_uniforms(uint64_t seed, uint32_t b, uint32_t p, uint32_t k, uint32_t do
 /* the same fixed sequence of IEEE operations (fma = one rounding).          */
 /* ------------------------------------------------------------------------- */
 
-/* log(x) for positive normal x.  Classic argument reduction x = 2^k (1+f),
- * sqrt(2)/2 <= 1+f < sqrt(2), s = f/(2+f), log(1+f) = 2s + s*R(s^2) with the
- * degree-7 minimax R of the FreeBSD/fdlibm family; error < 1 ulp. */
+/* log(x) for positive normal x, table-driven (structure of glibc's log; table generated by
+ * tools/gen_log_table.py, re-derived entry by entry in tests/test_oracle_numerics.py):
+ * x = 2^k z, z in [0.6875, 1.375); T[i] = (invc, logc) for the i-th of 128 subintervals;
+ * r = fma(z, invc, -1); log(x) = k ln2 + logc + r + r^2 (A0 + ... + A6 r^6).  Max error 1 ulp. */
 double orc_dlog(double x) {
-    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
-                        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                        Lg7 = 1.479819860511658591e-01;
-    uint64_t bits;
-    memcpy(&bits, &x, 8);
-    uint32_t hx = (uint32_t)(bits >> 32);
-    uint32_t lx = (uint32_t)bits;
-    int32_t k = (int32_t)(hx >> 20) - 1023;
-    hx &= 0x000fffffu;
-    uint32_t i = (hx + 0x95f64u) & 0x100000u; /* mantissa >= sqrt(2): halve it, bump k */
-    hx |= i ^ 0x3ff00000u;
-    k += (int32_t)(i >> 20);
-    bits = ((uint64_t)hx << 32) | lx;
-    double m;
-    memcpy(&m, &bits, 8);
-    double f = m - 1.0;
-    double hfsq = 0.5 * f * f;
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double w = z * z;
-    double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-    double R = t2 + t1;
-    double dk = (double)k;
-    double a = fma(dk, ln2_lo, s * (hfsq + R));
-    double b = (a - hfsq) + f;
-    return fma(dk, ln2_hi, b);
+    static const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
+    static const double A0 = -0.5, A1 = 0x1.5555555555555p-2, A2 = -0.25, A3 = 0x1.999999999999ap-3,
+                        A4 = -0x1.5555555555555p-3, A5 = 0x1.2492492492492p-3, A6 = -0.125;
+    uint64_t ix;
+    memcpy(&ix, &x, 8);
+    uint64_t tmp = ix - 0x3FE6000000000000ull;
+    int i = (int)((tmp >> 45) & 127);
+    int32_t k = (int32_t)((int64_t)tmp >> 52);
+    uint64_t iz = ix - (tmp & 0xFFF0000000000000ull);
+    double z;
+    memcpy(&z, &iz, 8);
+    double invc = kLogTable[i][0], logc = kLogTable[i][1];
+    double r = fma(z, invc, -1.0);
+    double kd = (double)k;
+    double w = fma(kd, Ln2hi, logc);
+    double hi = w + r;
+    double lo = fma(kd, Ln2lo, (w - hi) + r);
+    double r2 = r * r;
+    double p = fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, A6, A5), A4), A3), A2), A1), A0);
+    return fma(r2, p, lo) + hi;
 }
 
 /* exp(x) for -37 <= x <= 0 (callers cut off below -37, where the fixed-point weight

@@ -26,8 +26,8 @@ class Trace(C.Structure):
 
 def build(force: bool = False):
     src = os.path.join(HERE, "dpomp_oracle.c")
-    hdr = os.path.join(HERE, "..", "include", "dpomp.h")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, os.path.join(HERE, "..", "include", "dpomp.h"), os.path.join(HERE, "orc_log_table.h")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["make", "-C", HERE, "-B", "liboracle_dpomp.so"], stdout=subprocess.DEVNULL)
     return LIB
 
