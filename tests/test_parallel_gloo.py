@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: world_size-2 gloo process group, segments sharded over ranks, one
+all-gather of the log-likelihood vector.  The per-rank evaluator is the ORACLE here (tests may use
+it; on a GPU box the evaluator is ParticleFilter.loglik) -- what is under test is the sharding,
+the global segment index in the RNG key, and the collective."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dpomp_amd as dp
+    from dpomp_amd import parallel
+    from oracle import oracle as orc
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), y)
+    theta = np.stack([0.0025 + 0.0002 * np.arange(B), 0.08 + 0.01 * np.arange(B)])
+
+    def evaluate(th, base):
+        return np.array([orc.pf_loglik(desc, 256, th[:, j], seed=77, seg=base + j).ll for j in range(th.shape[1])])
+
+    full = parallel.sharded_loglik(evaluate, theta)
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 2, 1])
+def test_sharded_batch_equals_single_process(tmp_path, dp, orc, B):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), y)
+    theta = np.stack([0.0025 + 0.0002 * np.arange(B), 0.08 + 0.01 * np.arange(B)])
+    want = np.array([orc.pf_loglik(desc, 256, theta[:, b], seed=77, seg=b).ll for b in range(B)])
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npy")
+        assert np.array_equal(got, want)  # every rank holds the full, partition-invariant vector
+
+
+def test_shard_bounds_partition():
+    from dpomp_amd import parallel
+    for B in (1, 2, 5, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            blocks = [parallel.shard_bounds(B, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+            for b in range(B):
+                r = parallel.shard_of(b, B, world)
+                assert blocks[r][0] <= b < blocks[r][1]
+
+
+def test_single_process_is_identity(dp):
+    from dpomp_amd import parallel
+    th = np.array([[0.003, 0.004], [0.1, 0.2]])
+    out = parallel.sharded_loglik(lambda t, base: t[0] * 1000 + base, th)
+    assert np.array_equal(out, [3.0 + 0, 4.0 + 0])
