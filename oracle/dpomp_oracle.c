@@ -271,7 +271,8 @@ static int64_t gillespie_advance(const dpomp_model_desc* d, const double* theta,
  * `total_weight += exp(...)` (:29-30) is done by the caller from logw. */
 void orc_iterate_particles(const dpomp_model_desc* d, int64_t* pop, int64_t P, const double* theta,
                            int k, double t, double tmax, uint64_t seed, uint32_t seg, int mode,
-                           int nthreads, double* logw, uint64_t* events, uint32_t* status) {
+                           int nthreads, double* logw, uint64_t* events, uint32_t* status,
+                           int32_t* per_particle_events /* [P] or NULL */) {
     const int S = d->n_states;
     const int64_t cap = default_cap(d);
     uint64_t ev_total = 0;
@@ -293,6 +294,7 @@ void orc_iterate_particles(const dpomp_model_desc* d, int64_t* pop, int64_t P, c
             n = cap;
         }
         logw[p] = g;
+        if (per_particle_events) per_particle_events[p] = (int32_t)n;
         ev_total += (uint64_t)n;
         for (int i = 0; i < S; ++i) pop[p + P * i] = x[i]; /* :31 */
     }
@@ -346,6 +348,7 @@ typedef struct orc_trace {
     int64_t* states;        /* [T][nkeep][S] state of the first nkeep particles after
                                propagation to each observation (before resampling)       */
     int64_t nkeep;
+    int32_t* particle_events; /* [T][P] executed events per particle and interval (work-balance analysis) */
 } orc_trace;
 
 int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const double* theta,
@@ -376,7 +379,8 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
     for (int obs_i = ymin; obs_i <= ymax; ++obs_i) { /* :54 */
         const int k = obs_i - 1;
         orc_iterate_particles(d, pop, P, theta, k, t_prev, d->obs_time[k], seed, seg, mode,
-                              nthreads, logw, &events, &status); /* :56 */
+                              nthreads, logw, &events, &status,
+                              (tr && tr->particle_events) ? tr->particle_events + (int64_t)k * P : NULL); /* :56 */
         if (tr && tr->states)
             for (int64_t p = 0; p < tr->nkeep && p < P; ++p)
                 for (int i = 0; i < S; ++i)

@@ -21,7 +21,7 @@ DOMAIN_PROPAGATE, DOMAIN_RESAMPLE, DOMAIN_SIMULATE = 0, 1, 2
 class Trace(C.Structure):
     _fields_ = [("per_obs_ll", C.POINTER(C.c_double)), ("logw", C.POINTER(C.c_double)),
                 ("offspring_end", C.POINTER(C.c_int64)), ("ancestors", C.POINTER(C.c_int64)),
-                ("states", C.POINTER(C.c_int64)), ("nkeep", C.c_int64)]
+                ("states", C.POINTER(C.c_int64)), ("nkeep", C.c_int64), ("particle_events", C.POINTER(C.c_int32))]
 
 
 def build(force: bool = False):
@@ -140,7 +140,9 @@ def pf_partial(desc, pop, theta, ymin, ymax, seed=1, seg=0, mode=MODE_SPEC, rs_t
         r.offspring_end = np.zeros(P, dtype=np.int64)
         r.ancestors = np.zeros(P, dtype=np.int64)
         r.states = np.zeros((T, min(nkeep, P), S), dtype=np.int64)
-        tr = Trace(_dp(r.per_obs_ll), _dp(r.logw), _ip(r.offspring_end), _ip(r.ancestors), _ip(r.states), min(nkeep, P))
+        r.particle_events = np.zeros((T, P), dtype=np.int32)
+        tr = Trace(_dp(r.per_obs_ll), _dp(r.logw), _ip(r.offspring_end), _ip(r.ancestors), _ip(r.states), min(nkeep, P),
+                   r.particle_events.ctypes.data_as(C.POINTER(C.c_int32)))
     rc = lib().orc_pf_partial(C.addressof(desc.c), _ip(flat), P, _dp(th), ymin, ymax, seed, seg, mode, rs_type, nthreads,
                               C.byref(ll), C.byref(st), C.byref(ev), C.byref(tr) if tr is not None else None)
     if rc != 0:
