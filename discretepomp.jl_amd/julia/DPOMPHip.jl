@@ -1,0 +1,206 @@
+# DPOMPHip.jl -- the reference-side binding a DiscretePOMP.jl maintainer would add: the bootstrap
+# particle filter behind `get_particle_filter_lpdf` / `partial_log_likelihood!` served by
+# libdpomp_hip.so through `ccall` (C ABI: include/dpomp.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: the build image has no Julia.  The tested twin of this file
+# is the ctypes host in discretepomp.jl_amd/_abi.py + particle_filter.py, which marshals the same
+# struct and calls the same entry points.
+module DPOMPHip
+
+import DiscretePOMP
+
+const LIB = get(ENV, "DPOMP_HIP_LIB", joinpath(@__DIR__, "..", "libdpomp_hip.so"))
+
+const MAX_STATES = 8
+const MAX_EVENTS = 8
+const MAX_FACTORS = 2
+
+struct RateTermC            # dpomp_rate_term
+    theta_index::Int32      # 0-based
+    form::Int32             # 0 = ((θ·f0)·f1)/d ; 1 = θ·((f0·f1)/d)
+    n_factors::Int32
+    factor_mask::NTuple{MAX_FACTORS,UInt32}
+    denom_mask::UInt32
+end
+
+struct ObsModelC            # dpomp_obs_model
+    kind::Int32             # 1 = partial_gaussian_obs_model
+    state_mask::UInt32
+    value_mask::UInt32
+    reserved::Int32
+    sigma::Float64
+end
+
+struct ModelDescC           # dpomp_model_desc (field order and padding as in include/dpomp.h)
+    abi_version::Int32
+    n_states::Int32
+    n_events::Int32
+    n_params::Int32
+    builtin_id::Int32
+    t0_index::Int32
+    initial_condition::NTuple{MAX_STATES,Int64}
+    transition::NTuple{MAX_EVENTS * MAX_STATES,Int32}   # transition[e][s], row-major
+    rate::NTuple{MAX_EVENTS,RateTermC}
+    obs::ObsModelC
+    n_obs::Int32
+    n_obs_values::Int32
+    obs_time::Ptr{Float64}
+    obs_id::Ptr{Int64}
+    obs_value::Ptr{Int64}
+    max_events_per_interval::Int64
+end
+
+# catalogue name (DPOMPModel.model_name as stored by generate_model, src/hmm_examples.jl:171-204)
+# -> (builtin id dd, builtin id fd, rate table).  A term is (θ index, factors, denominator, form), 1-based.
+mask(idx) = isempty(idx) ? UInt32(0) : reduce(|, (UInt32(1) << (i - 1) for i in idx))
+term(th, factors, denom = (), form = 0) =
+    RateTermC(th - 1, form, length(factors),
+              ntuple(i -> i <= length(factors) ? mask(factors[i]) : UInt32(0), MAX_FACTORS), mask(denom))
+
+const CATALOGUE = Dict(
+    "SI" => (1, 5, [term(1, ((1,), (2,)))]),
+    "SIR" => (2, 6, [term(1, ((1,), (2,))), term(2, ((2,),))]),
+    "SIS" => (2, 6, [term(1, ((1,), (2,))), term(2, ((2,),))]),
+    "SEI" => (3, 7, [term(1, ((1,), (3,))), term(2, ((2,),))]),
+    "SEIR" => (4, 8, [term(1, ((1,), (3,))), term(2, ((2,),)), term(3, ((3,),))]),
+    "SEIS" => (4, 8, [term(1, ((1,), (3,))), term(2, ((2,),)), term(3, ((3,),))]),
+    "PN" => (9, 9, [term(1, ((2,),)), term(2, ((1,), (2,))), term(3, ((1,),))]),
+    "SIAB" => (10, 10, [term(1, ((3, 4),)), term(1, ((3,),)), term(1, ((4,),)),
+                        term(2, ((1,), (4,)), (1, 2), 1), term(3, ((2,), (3,)), (3, 4), 1), term(4, ((2,),))]),
+)
+
+mutable struct Filter
+    handle::Ptr{Cvoid}
+    keep::Any          # arrays the descriptor points to
+    n_params::Int
+    n_obs::Int
+end
+
+check(h, rc) = rc == 0 ? nothing :
+    error("dpomp: ", unsafe_string(ccall((:dpomp_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
+
+"""
+    Filter(model::DPOMPModel, y::Vector{Observation}; freq_dep=false, obs_error=2.0, seq=nothing, device=0)
+
+Flattens a catalogue `DPOMPModel` and its data (what `get_private_model` does for the Julia filter,
+src/DiscretePOMP.jl:96-99).  The observation model must be `partial_gaussian_obs_model`; since a Julia
+closure cannot be inspected, its parameters are passed again (`obs_error`, `seq`; defaults follow
+`generate_model`).
+"""
+function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observation};
+                freq_dep::Bool = false, obs_error::Float64 = 2.0, seq = nothing, device::Integer = 0)
+    haskey(CATALOGUE, model.model_name) || error("no device rate table for model '$(model.model_name)'")
+    b_dd, b_fd, terms = CATALOGUE[model.model_name]
+    S, E = length(model.initial_condition), size(model.m_transition, 1)
+    terms = copy(terms)
+    if freq_dep && b_fd != b_dd
+        t = terms[1]
+        terms[1] = RateTermC(t.theta_index, 0, t.n_factors, t.factor_mask, mask(1:S))
+    end
+    K = max(maximum(t.theta_index for t in terms) + 1, model.t0_index)
+    seq === nothing && (seq = model.model_name in ("SEI", "SEIR", "SEIS") ? (3,) : (2,))
+    V = length(y[1].val)
+    obs_time = Float64[o.time for o in y]
+    obs_id = Int64[o.obs_id for o in y]
+    obs_value = Int64[o.val[v] for o in y for v in 1:V]           # observation-major
+    pad(v, n, z) = ntuple(i -> i <= length(v) ? v[i] : z, n)
+    trans = zeros(Int32, MAX_EVENTS * MAX_STATES)
+    for e in 1:E, s in 1:S
+        trans[(e - 1) * MAX_STATES + s] = model.m_transition[e, s]
+    end
+    zero_term = RateTermC(0, 0, 0, (UInt32(0), UInt32(0)), UInt32(0))
+    desc = Ref(ModelDescC(1, S, E, K, freq_dep ? b_fd : b_dd, model.t0_index,
+                          pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
+                          pad(terms, MAX_EVENTS, zero_term),
+                          ObsModelC(1, mask(seq), mask(seq), 0, obs_error),
+                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve obs_time obs_id obs_value begin
+        rc = ccall((:dpomp_create, LIB), Cint, (Ref{ModelDescC}, Cint, Ref{Ptr{Cvoid}}), desc, device, h)
+    end
+    rc == 0 || error("dpomp_create: ", unsafe_string(ccall((:dpomp_last_global_error, LIB), Cstring, ())))
+    f = Filter(h[], (obs_time, obs_id, obs_value), K, length(y))
+    finalizer(x -> ccall((:dpomp_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    return f
+end
+
+"""
+    get_particle_filter_lpdf(model, obs_data; np=200, rs_type=1, essc=0.3, seed=1) -> θ -> Float64
+
+Drop-in for `DiscretePOMP.get_particle_filter_lpdf` (src/hmm_utils.jl:281-284).
+"""
+function get_particle_filter_lpdf(model, obs_data; np::Int64 = 200, rs_type::Int64 = 1, essc::Float64 = 0.3,
+                                  seed::Integer = 1, kwargs...)
+    f = Filter(model, obs_data; kwargs...)
+    check(f.handle, ccall((:dpomp_set_resampler, LIB), Cint, (Ptr{Cvoid}, Cint), f.handle, rs_type))
+    calls = Ref(UInt64(0))
+    function comp_log_pdf(parameters::Array{Float64,1})
+        out = Ref(0.0)
+        s = UInt64(seed) * 0x9E3779B97F4A7C15 + calls[]
+        calls[] += 1
+        GC.@preserve parameters begin
+            check(f.handle, ccall((:dpomp_pf_loglik, LIB), Cint,
+                  (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Int64, Ref{Float64}, Ptr{UInt32}),
+                  f.handle, parameters, 1, np, s, 0, out, C_NULL))
+        end
+        return out[]
+    end
+    return comp_log_pdf
+end
+
+"""
+    loglik(f, theta::Matrix{Float64}, np; seed, seg_base=0) -> Vector{Float64}
+
+B independent filters in one call: `theta` is K x B (Julia's column-major layout IS the ABI's).
+"""
+function loglik(f::Filter, theta::Matrix{Float64}, np::Integer; seed::Integer = 1, seg_base::Integer = 0)
+    B = size(theta, 2)
+    out = Vector{Float64}(undef, B)
+    GC.@preserve theta out check(f.handle, ccall((:dpomp_pf_loglik, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Int64, Ptr{Float64}, Ptr{UInt32}),
+        f.handle, theta, B, np, seed, seg_base, out, C_NULL))
+    return out
+end
+
+# Device-resident populations: the `pop[p]` matrices run_pibis keeps per θ-particle (src/hmm_ibis.jl:26-30).
+mutable struct Population
+    f::Filter
+    ptr::Ptr{Cvoid}
+    B::Int
+    P::Int
+end
+
+function Population(f::Filter, B::Integer, P::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(f.handle, ccall((:dpomp_pop_alloc, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), f.handle, B, P, p))
+    pop = Population(f, p[], B, P)
+    finalizer(x -> ccall((:dpomp_pop_free, LIB), Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}), x.f.handle, x.ptr), pop)
+    return pop
+end
+
+"partial_log_likelihood!(pop[p], model, θ[:,p], fn_rs, essc, ymin, ymax) for every p at once (src/hmm_ibis.jl:53-56)."
+function partial_log_likelihood!(pop::Population, theta::Matrix{Float64}, ymin::Integer, ymax::Integer;
+                                 seed::Integer = 1, seg_base::Integer = 0)
+    out = Vector{Float64}(undef, pop.B)
+    GC.@preserve theta out check(pop.f.handle, ccall((:dpomp_pf_partial, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, UInt64, Int64, Ptr{Float64}, Ptr{UInt32}),
+        pop.f.handle, pop.ptr, theta, ymin, ymax, seed, seg_base, out, C_NULL))
+    return out
+end
+
+"θ-level resampling copy `pop[p] = pop[ancestor[p]]` (src/hmm_ibis.jl:71-75); `ancestors` 1-based."
+function gather!(pop::Population, ancestors::Vector{Int64})
+    a0 = ancestors .- 1
+    GC.@preserve a0 check(pop.f.handle, ccall((:dpomp_pop_gather, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}),
+                                              pop.f.handle, pop.ptr, a0))
+end
+
+"Segment b (1-based) as the reference's P x S `Array{Int64,2}`."
+function download(pop::Population, b::Integer, S::Integer)
+    out = Array{Int64,2}(undef, pop.P, S)
+    GC.@preserve out check(pop.f.handle, ccall((:dpomp_pop_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}),
+                                               pop.f.handle, pop.ptr, b - 1, out))
+    return out
+end
+
+end # module
