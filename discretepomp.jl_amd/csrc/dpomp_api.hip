@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,39 +26,49 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 
 typedef void (*PropFn)(PropArgs);
 
+constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
+constexpr int kGatherLdsMaxTiles = 8192;  // k_gather: tile boundaries (4 B each) + 16 KB window must fit LDS
+
+// Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
+// particles per lane (chosen by how many particles the launch has, see pick_prop).
+struct PropSet {
+    PropFn fn1, q2, q4;
+};
+#define DPOMP_PROPSET(...) {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>}
+
 struct PropEntry {
     int builtin, S, E;
-    PropFn fn;
+    PropSet set;
 };
 
 // (rate evaluator, S, E) instances compiled for the catalogue of generate_model
 // (src/hmm_examples.jl:171-204); anything else runs the table-driven RGeneric.
 const PropEntry kPropTable[] = {
-    {DPOMP_BUILTIN_SI, 2, 1, k_propagate<RSi<false>>},
-    {DPOMP_BUILTIN_SI_FD, 2, 1, k_propagate<RSi<true>>},
-    {DPOMP_BUILTIN_SIR, 3, 2, k_propagate<RSir<3, false>>},
-    {DPOMP_BUILTIN_SIR, 2, 2, k_propagate<RSir<2, false>>},
-    {DPOMP_BUILTIN_SIR_FD, 3, 2, k_propagate<RSir<3, true>>},
-    {DPOMP_BUILTIN_SIR_FD, 2, 2, k_propagate<RSir<2, true>>},
-    {DPOMP_BUILTIN_SEI, 3, 2, k_propagate<RSei<false>>},
-    {DPOMP_BUILTIN_SEI_FD, 3, 2, k_propagate<RSei<true>>},
-    {DPOMP_BUILTIN_SEIR, 4, 3, k_propagate<RSeir<4, false>>},
-    {DPOMP_BUILTIN_SEIR, 3, 3, k_propagate<RSeir<3, false>>},
-    {DPOMP_BUILTIN_SEIR_FD, 4, 3, k_propagate<RSeir<4, true>>},
-    {DPOMP_BUILTIN_SEIR_FD, 3, 3, k_propagate<RSeir<3, true>>},
-    {DPOMP_BUILTIN_LOTKA, 2, 3, k_propagate<RLotka>},
-    {DPOMP_BUILTIN_ROSSMAC, 4, 6, k_propagate<RRossmac>},
+    {DPOMP_BUILTIN_SI, 2, 1, DPOMP_PROPSET(RSi<false>)},
+    {DPOMP_BUILTIN_SI_FD, 2, 1, DPOMP_PROPSET(RSi<true>)},
+    {DPOMP_BUILTIN_SIR, 3, 2, DPOMP_PROPSET(RSir<3, false>)},
+    {DPOMP_BUILTIN_SIR, 2, 2, DPOMP_PROPSET(RSir<2, false>)},
+    {DPOMP_BUILTIN_SIR_FD, 3, 2, DPOMP_PROPSET(RSir<3, true>)},
+    {DPOMP_BUILTIN_SIR_FD, 2, 2, DPOMP_PROPSET(RSir<2, true>)},
+    {DPOMP_BUILTIN_SEI, 3, 2, DPOMP_PROPSET(RSei<false>)},
+    {DPOMP_BUILTIN_SEI_FD, 3, 2, DPOMP_PROPSET(RSei<true>)},
+    {DPOMP_BUILTIN_SEIR, 4, 3, DPOMP_PROPSET(RSeir<4, false>)},
+    {DPOMP_BUILTIN_SEIR, 3, 3, DPOMP_PROPSET(RSeir<3, false>)},
+    {DPOMP_BUILTIN_SEIR_FD, 4, 3, DPOMP_PROPSET(RSeir<4, true>)},
+    {DPOMP_BUILTIN_SEIR_FD, 3, 3, DPOMP_PROPSET(RSeir<3, true>)},
+    {DPOMP_BUILTIN_LOTKA, 2, 3, DPOMP_PROPSET(RLotka)},
+    {DPOMP_BUILTIN_ROSSMAC, 4, 6, DPOMP_PROPSET(RRossmac)},
 };
 
-PropFn generic_fn(int S, int E) {
+PropSet generic_set(int S, int E) {
     const int s = S <= 2 ? 2 : (S <= 4 ? 4 : 8);
     const int e = E <= 2 ? 2 : (E <= 4 ? 4 : 8);
 #define DPOMP_G(SS, EE) \
-    if (s == SS && e == EE) return k_propagate<RGeneric<SS, EE>>;
+    if (s == SS && e == EE) return PropSet DPOMP_PROPSET(RGeneric<SS, EE>);
     DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
     DPOMP_G(8, 4) DPOMP_G(8, 8)
 #undef DPOMP_G
-    return nullptr;
+    return PropSet{nullptr, nullptr, nullptr};
 }
 
 struct KernelStat {
@@ -81,8 +92,9 @@ struct dpomp_handle {
     std::vector<double> obs_time;
     std::vector<int64_t> obs_id;
     std::vector<long long> ysum;
-    PropFn prop_fn = nullptr;
+    PropSet prop{nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
+    int force_rpl = 0;  // 0 = choose by launch size; 1, 2, 4 = force (tests, tuning)
     int rs_type = DPOMP_RS_SYSTEMATIC;
     bool profiling = false;
     KernelStat stats[KID_COUNT];
@@ -104,6 +116,7 @@ struct dpomp_pop {
     int32_t* offs = nullptr;
     unsigned long long* blocksum = nullptr;
     unsigned long long* blockprefix = nullptr;
+    int32_t* tile_end = nullptr;           // [B][nblk]
     unsigned long long* segmax = nullptr;  // [T][B]
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]
@@ -218,6 +231,7 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->offs);
     (void)hipFree(p->blocksum);
     (void)hipFree(p->blockprefix);
+    (void)hipFree(p->tile_end);
     (void)hipFree(p->segmax);
     (void)hipFree(p->wtot);
     (void)hipFree(p->ll);
@@ -255,6 +269,7 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->offs, (size_t)B * p->Pp * sizeof(int32_t));
     DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
+    DPOMP_ALLOC(p->tile_end, (size_t)B * p->nblk * 4);
     DPOMP_ALLOC(p->segmax, (size_t)p->T * B * 8);
     DPOMP_ALLOC(p->wtot, (size_t)B * 8);
     DPOMP_ALLOC(p->ll, (size_t)B * 8);
@@ -319,8 +334,16 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.use_theta_t0 = (obs_i == 1 && h->dm.t0_index > 0) ? 1 : 0;
         a.want_weight = weighted ? 1 : 0;
         {
+            // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
+            int rpl = h->force_rpl;
+            if (rpl != 1 && rpl != 2 && rpl != 4) {
+                const int64_t waves1 = B * ((p->P + 63) / 64);
+                rpl = waves1 >= 16384 ? 4 : (waves1 >= 8192 ? 2 : 1);
+            }
+            PropFn fn = rpl == 4 ? h->prop.q4 : (rpl == 2 ? h->prop.q2 : h->prop.fn1);
+            const int64_t chunk = (int64_t)kBlock * rpl;
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
-            hipLaunchKernelGGL(h->prop_fn, dim3((unsigned)((p->P + kBlock - 1) / kBlock), (unsigned)B), block, 0, st, a);
+            hipLaunchKernelGGL(fn, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, 0, st, a);
         }
         if (record_states)
             HIPCHK(h, hipMemcpyAsync(record_states + (size_t)k * B * p->S * p->Pp, p->state[p->cur],
@@ -336,6 +359,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.ll = p->ll;
             w.status = p->status;
             w.offs = p->offs;
+            w.tile_end = p->tile_end;
             w.Pp = p->Pp;
             w.P = (int32_t)p->P;
             w.nblk = p->nblk;
@@ -347,25 +371,35 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                 ScopedTiming tm(h, KID_WSUM);
                 hipLaunchKernelGGL(k_wsum, grid_tiles, block, 0, st, w);
             }
-            {
+            const bool resample = obs_i < T;  // :62  (the ESS criterion is commented out in the reference, :63-68)
+            const bool fused = resample && p->nblk <= kFusedScanMaxTiles;
+            if (!fused) {
                 ScopedTiming tm(h, KID_SCAN_BLOCKS);  // output += log(cum_weight[end]/P)  :60
                 hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)B), block, 0, st, w);
             }
-            if (obs_i < T) {  // :62  (the ESS criterion is commented out in the reference, :63-68)
+            if (resample) {
                 {
-                    ScopedTiming tm(h, KID_OFFSETS);
-                    hipLaunchKernelGGL(k_offsets, grid_tiles, block, 0, st, w);
+                    ScopedTiming tm(h, KID_OFFSETS);  // fused: also the tile-sum scan and the :60 update
+                    if (fused) hipLaunchKernelGGL(k_offsets<true>, grid_tiles, block, 0, st, w);
+                    else hipLaunchKernelGGL(k_offsets<false>, grid_tiles, block, 0, st, w);
                 }
                 GatherArgs g;
                 g.src = p->state[p->cur];
                 g.dst = p->state[p->cur ^ 1];
                 g.offs = p->offs;
+                g.tile_end = p->tile_end;
                 g.Pp = p->Pp;
                 g.P = (int32_t)p->P;
                 g.S = p->S;
+                g.nblk = p->nblk;
                 {
                     ScopedTiming tm(h, KID_GATHER);  // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67
-                    hipLaunchKernelGGL(k_gather, grid_tiles, block, 0, st, g);
+                    if (p->nblk <= kGatherLdsMaxTiles) {
+                        const size_t lds = (size_t)(kStageTiles * kTile + p->nblk) * sizeof(int32_t);
+                        hipLaunchKernelGGL(k_gather, grid_tiles, block, lds, st, g);
+                    } else {
+                        hipLaunchKernelGGL(k_gather_global, grid_tiles, block, 0, st, g);
+                    }
                 }
                 p->cur ^= 1;
             }
@@ -449,13 +483,13 @@ int dpomp_create(const dpomp_model_desc* d, int device, dpomp_handle** out) {
         m.rate[ev] = {t.theta_index, t.form, t.n_factors, t.factor_mask[0], t.factor_mask[1], t.denom_mask};
         m.x0[ev] = ev < d->n_states ? (int32_t)d->initial_condition[ev] : 0;
     }
-    h->prop_fn = nullptr;
     for (const PropEntry& pe : kPropTable)
-        if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop_fn = pe.fn;
-    if (!h->prop_fn) {
-        h->prop_fn = generic_fn(d->n_states, d->n_events);
+        if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
+    if (!h->prop.fn1) {
+        h->prop = generic_set(d->n_states, d->n_events);
         h->prop_is_generic = true;
     }
+    if (const char* env = getenv("DPOMP_RPL")) h->force_rpl = atoi(env);
     *out = h;
     return DPOMP_OK;
 }
@@ -481,6 +515,13 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type) {
     if (!h) return DPOMP_EINVAL;
     if (rs_type < DPOMP_RS_SYSTEMATIC || rs_type > DPOMP_RS_MULTINOMIAL) return fail(h, DPOMP_EINVAL, "rs_type %d unknown", rs_type);
     h->rs_type = rs_type;
+    return DPOMP_OK;
+}
+
+int dpomp_set_particles_per_lane(dpomp_handle* h, int rpl) {
+    if (!h) return DPOMP_EINVAL;
+    if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4) return fail(h, DPOMP_EINVAL, "particles_per_lane must be 0, 1, 2 or 4");
+    h->force_rpl = rpl;
     return DPOMP_OK;
 }
 

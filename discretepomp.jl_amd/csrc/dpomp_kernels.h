@@ -311,6 +311,169 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     }
 }
 
+// ---- k_propagate_q: the same computation with dynamic lane refill --------------------------------
+// One particle per lane wastes lanes: event counts per interval vary (Pooley SIS: 52 +- 50 in the
+// first interval, 269 +- 16 later), so a wave runs until its slowest lane is done (measured lane
+// utilisation 79 %).  Here a workgroup owns a chunk of C = 256*RPL particles.  Phase 0 stages the
+// chunk in LDS with coalesced loads: state tile [S][C] and the Philox-seeded stream state of every
+// particle (full lane occupancy for the 10 Philox rounds).  Phase 1: lanes pop the next particle
+// index from an LDS queue whenever they finish one (LDS atomic + 2 LDS reads, no global memory, no
+// Philox), write the final state back to the LDS tile.  Phase 2: weights, coalesced write-back and
+// the reductions, again at full occupancy.  Which lane runs which particle is irrelevant to the
+// result because every draw is keyed by the particle index: still bit-identical to the oracle.
+template <class R, int RPL>
+__global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
+    constexpr int S = R::S, E = R::E;
+    constexpr int C = kBlock * RPL;
+    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    __shared__ double s_log[128][2];
+    __shared__ int32_t s_x[S][C];
+    __shared__ uint4 s_seed[C];
+    __shared__ int32_t s_cnt[C];  // executed events, bit 31 = hit the event cap
+    __shared__ int s_next;
+    __shared__ double s_max[kBlock / 64];
+    __shared__ unsigned long long s_ev[kBlock / 64];
+    __shared__ int s_cap[kBlock / 64];
+
+    const int b = blockIdx.y;
+    const int base = blockIdx.x * C;
+    const int cnt = min(C, a.P - base);
+    const int s_real = R::kGeneric ? a.m.S : S;
+    int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
+    const double* th = a.theta + (int64_t)b * a.m.K;
+
+    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+#pragma unroll
+    for (int jj = 0; jj < RPL; ++jj) {
+        const int idx = jj * kBlock + threadIdx.x;
+        if (idx < cnt) {
+            const int p = base + idx;
+#pragma unroll
+            for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
+            const Stream r = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
+            s_seed[idx] = make_uint4((uint32_t)r.s0, (uint32_t)(r.s0 >> 32), (uint32_t)r.s1, (uint32_t)(r.s1 >> 32));
+        }
+    }
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+
+    const double t_start = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
+    const double tmax = a.t_max;
+    const int e_real = R::kGeneric ? a.m.E : E;
+    const int cap = a.m.cap;
+    int x[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = 0;
+    Stream rng{0, 0};
+    double time = 0.0;
+    int n = 0, cur = 0;
+    bool active = false, exhausted = false;
+    for (;;) {
+        if (!active && !exhausted) {
+            const int idx = atomicAdd(&s_next, 1);
+            if (idx < cnt) {
+                cur = idx;
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
+                const uint4 sd = s_seed[idx];
+                rng.s0 = (uint64_t)sd.x | ((uint64_t)sd.y << 32);
+                rng.s1 = (uint64_t)sd.z | ((uint64_t)sd.w << 32);
+                time = t_start;
+                n = 0;
+                active = true;
+            } else {
+                exhausted = true;
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {
+            double cum[E];
+            R::rates(a.m, th, x, cum);
+#pragma unroll
+            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+            const double tot = cum[E - 1];
+            bool done = (tot == 0.0), capped = false;
+            if (!done) {
+                const double u1 = u01(stream_next(rng));
+                time = time - dlog_tab(u1, s_log) / tot;
+                done = time > tmax;
+                if (!done) {
+                    const double etc = u01(stream_next(rng)) * tot;
+                    TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+                    for (int i = E - 2; i >= 0; --i) {
+                        const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                        if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
+                    }
+#pragma unroll
+                    for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+                    if (++n >= cap) done = capped = true;
+                }
+            }
+            if (done) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) s_x[s][cur] = x[s];
+                s_cnt[cur] = n | (capped ? (int)0x80000000 : 0);
+                active = false;
+            }
+        }
+    }
+    __syncthreads();
+
+    double gmax = -__builtin_inf();
+    unsigned long long ev = 0;
+    bool any_cap = false;
+#pragma unroll
+    for (int jj = 0; jj < RPL; ++jj) {
+        const int idx = jj * kBlock + threadIdx.x;
+        if (idx < cnt) {
+            const int p = base + idx;
+            int xs = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int v = s_x[s][idx];
+                if (s < s_real) st[(int64_t)s * a.Pp + p] = v;
+                if (a.m.obs_state_mask & (1u << s)) xs += v;
+            }
+            const int c = s_cnt[idx];
+            ev += (unsigned long long)(c & 0x7FFFFFFF);
+            const bool capped = c < 0;
+            any_cap |= capped;
+            if (a.want_weight) {
+                const long long d = a.ysum - (long long)xs;
+                double g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+                if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
+                a.logw[(int64_t)b * a.Pp + p] = g;
+                gmax = fmax(gmax, g);
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double wm = wave_max(gmax);
+    const unsigned long long wev = wave_sum(ev);
+    const int wcap = __any(any_cap);
+    if (lane == 0) {
+        s_max[wid] = wm;
+        s_ev[wid] = wev;
+        s_cap[wid] = wcap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bm = s_max[0];
+        unsigned long long be = s_ev[0];
+        int bc = s_cap[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) {
+            bm = fmax(bm, s_max[w]);
+            be += s_ev[w];
+            bc |= s_cap[w];
+        }
+        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (be) atomicAdd(a.events, be);
+        if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+    }
+}
+
 // ---- weights -----------------------------------------------------------------------------------
 struct WeightArgs {
     const double* logw;                 // [B][Pp]
@@ -321,6 +484,7 @@ struct WeightArgs {
     double* ll;                         // [B] running log-likelihood
     uint32_t* status;                   // [B]
     int32_t* offs;                      // [B][Pp]
+    int32_t* tile_end;                  // [B][nblk] N of the last particle of each 1024-tile
     int64_t Pp;
     int32_t P, nblk, sh;
     uint32_t obs_k, seg_base;
@@ -388,27 +552,63 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
     }
 }
 
-// k_offsets: inclusive fixed-point cumulative weight c_j of every particle (tile scan + tile
+// k_offsets<FUSED>: inclusive fixed-point cumulative weight c_j of every particle (tile scan + tile
 // prefix) -> offspring boundary N_j.  Slots [N_{j-1}, N_j) of the resampled population copy
 // particle j: rsp_systematic's u_i = (u1 + (i-1)/P) cw[end], `while u[i] > cw[j]`
 // (hmm_pf_resample.jl:27-37) solved for i instead of walked.
+// FUSED: every workgroup sums the (<= 2048) tile sums itself -- its own exclusive prefix and the
+// total W -- so no separate scan launch is needed; workgroup 0 also adds the log mean weight to
+// the running log-likelihood (hmm_particle_filter.jl:60).  Otherwise the prefix and W come from
+// k_scan_blocks.  Also writes tile_end[blk] = N of the tile's last particle for k_gather.
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     const int b = blockIdx.y, blk = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ unsigned long long s_w[kBlock / 64], s_pre[kBlock / 64], s_tot[kBlock / 64];
+    unsigned long long tile_prefix, W;
+    if (FUSED) {
+        const unsigned long long* bs = a.blocksum + (int64_t)b * a.nblk;
+        unsigned long long pre = 0, tot = 0;
+        for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
+            const unsigned long long v = bs[i];
+            tot += v;
+            if (i < blk) pre += v;
+        }
+        pre = wave_sum(pre);
+        tot = wave_sum(tot);
+        if (lane == 0) {
+            s_pre[wid] = pre;
+            s_tot[wid] = tot;
+        }
+    }
     unsigned long long w[kItems];
     load_tile_weights(a, b, blk, w);
     unsigned long long c[kItems];
     c[0] = w[0];
 #pragma unroll
     for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + w[q];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
-    __shared__ unsigned long long s_w[kBlock / 64];
     if (lane == 63) s_w[wid] = incl;
     __syncthreads();
-    unsigned long long base = a.blockprefix[(int64_t)b * a.nblk + blk] + (incl - c[kItems - 1]);
+    if (FUSED) {
+        tile_prefix = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
+        W = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+        if (blk == 0 && threadIdx.x == 0) {
+            a.wtot[b] = W;
+            if (W == 0) {
+                a.ll[b] += -__builtin_inf();
+                atomicOr(&a.status[b], 2u /* DPOMP_ST_ZERO_WEIGHT */);
+            } else {
+                a.ll[b] += log_mean_weight(ordered_value(a.segmax[b]), W, a.sh, a.P);
+            }
+        }
+    } else {
+        tile_prefix = a.blockprefix[(int64_t)b * a.nblk + blk];
+        W = a.wtot[b];
+    }
+    unsigned long long base = tile_prefix + (incl - c[kItems - 1]);
     for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
 
-    const unsigned long long W = a.wtot[b];
     Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
     const double r = u01(stream_next(rs));  // rand() of hmm_pf_resample.jl:27
     int n[kItems];
@@ -417,21 +617,30 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
     *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
+    if (threadIdx.x == kBlock - 1) a.tile_end[(int64_t)b * a.nblk + blk] = n[kItems - 1];
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------
-// Ancestor of slot i = first j with N_j > i (binary search over the monotone boundaries).
-// Writes are 16 B per lane per component; reads are monotone in i.
+// Ancestor of slot i = first j with N_j > i.  N is monotone, so the 1024 output slots of a
+// workgroup draw from a contiguous window of parents.  The workgroup stages (a) the per-tile
+// boundary array tile_end (4 B per 1024 particles) and (b) the window of N it needs (up to
+// kStageTiles tiles) in LDS and every lane searches there (12 LDS steps, 4 searches interleaved);
+// wider windows (very uneven weights) fall back to tile_end in LDS + a 10-step search in L2.
+// Writes are 16 B per lane per component, reads of the parents are monotone in i.
 struct GatherArgs {
     const int32_t* src;  // [B][S][Pp]
     int32_t* dst;
-    const int32_t* offs;  // [B][Pp]
+    const int32_t* offs;      // [B][Pp]
+    const int32_t* tile_end;  // [B][nblk]
     int64_t Pp;
-    int32_t P, S;
+    int32_t P, S, nblk;
 };
 
-__device__ __forceinline__ int first_greater(const int32_t* __restrict__ N, int P, int i) {
-    int lo = 0, hi = P - 1;
+constexpr int kStageTiles = 4;
+
+template <class Ptr>
+__device__ __forceinline__ int first_greater(Ptr N, int n, int i) {
+    int lo = 0, hi = n - 1;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (N[mid] > i) hi = mid; else lo = mid + 1;
@@ -439,13 +648,69 @@ __device__ __forceinline__ int first_greater(const int32_t* __restrict__ N, int 
     return lo;
 }
 
-__global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
+// General form: global binary search per slot (any P; used when tile_end does not fit in LDS).
+__global__ __launch_bounds__(kBlock) void k_gather_global(GatherArgs a) {
     const int b = blockIdx.y;
     const int64_t i0 = (int64_t)blockIdx.x * kTile + threadIdx.x * kItems;
     const int32_t* N = a.offs + (int64_t)b * a.Pp;
     int j[kItems];
 #pragma unroll
     for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? first_greater(N, a.P, (int)(i0 + q)) : 0;
+    for (int s = 0; s < a.S; ++s) {
+        const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
+        const int4 v = make_int4(src[j[0]], src[j[1]], src[j[2]], src[j[3]]);
+        *reinterpret_cast<int4*>(a.dst + ((int64_t)b * a.S + s) * a.Pp + i0) = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
+    int32_t* s_n = smem;                               // [kStageTiles * kTile] staged window of N
+    int32_t* s_te = smem + kStageTiles * kTile;        // [nblk] tile boundaries
+    __shared__ int s_tlo, s_thi;
+    const int b = blockIdx.y;
+    const int tile0 = blockIdx.x * kTile;
+    const int64_t i0 = (int64_t)tile0 + threadIdx.x * kItems;
+    const int32_t* N = a.offs + (int64_t)b * a.Pp;
+    const int32_t* TE = a.tile_end + (int64_t)b * a.nblk;
+    for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_te[t] = TE[t];
+    __syncthreads();
+    if (threadIdx.x == 0) s_tlo = first_greater(s_te, a.nblk, tile0);
+    if (threadIdx.x == 64) s_thi = first_greater(s_te, a.nblk, min(tile0 + kTile - 1, a.P - 1));
+    __syncthreads();
+    const int tlo = s_tlo, thi = s_thi;
+    const int ntiles = thi - tlo + 1;
+    int j[kItems];
+    if (ntiles <= kStageTiles) {
+        const int4* gsrc = reinterpret_cast<const int4*>(N + (int64_t)tlo * kTile);
+        int4* ldst = reinterpret_cast<int4*>(s_n);
+        for (int t = threadIdx.x; t < ntiles * (kTile / 4); t += kBlock) ldst[t] = gsrc[t];
+        __syncthreads();
+        const int M = ntiles * kTile;
+        int lo[kItems];
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) lo[q] = 0;
+#pragma unroll
+        for (int step = kStageTiles * kTile / 2; step > 0; step >>= 1) {
+#pragma unroll
+            for (int q = 0; q < kItems; ++q) {  // lo = number of staged boundaries <= slot
+                const int mid = lo[q] + step;
+                if (mid <= M && s_n[mid - 1] <= (int)(i0 + q)) lo[q] = mid;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? tlo * kTile + lo[q] : 0;
+    } else {
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) {
+            if (i0 + q < a.P) {
+                const int t = first_greater(s_te, a.nblk, (int)(i0 + q));
+                j[q] = t * kTile + first_greater(N + (int64_t)t * kTile, kTile, (int)(i0 + q));
+            } else {
+                j[q] = 0;
+            }
+        }
+    }
     for (int s = 0; s < a.S; ++s) {
         const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
         const int4 v = make_int4(src[j[0]], src[j[1]], src[j[2]], src[j[3]]);

@@ -86,6 +86,34 @@ DPOMP_HD Stream stream_init(uint64_t seed, uint32_t seg, uint32_t particle, uint
 DPOMP_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
 // xoroshiro128++ step.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Same function on 32-bit halves: every 64-bit rotate/shift is two v_alignbit_b32 (full rate)
+// instead of a 64-bit shift + shift + or, and the three-way xor is one v_xor3_b32 per half.
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh) low word
+}
+__device__ __forceinline__ uint64_t stream_next(Stream& s) {
+    const uint32_t a_lo = (uint32_t)s.s0, a_hi = (uint32_t)(s.s0 >> 32);
+    uint32_t b_lo = (uint32_t)s.s1, b_hi = (uint32_t)(s.s1 >> 32);
+    const uint64_t sum = s.s0 + s.s1;
+    const uint32_t m_lo = (uint32_t)sum, m_hi = (uint32_t)(sum >> 32);
+    // rotl(sum, 17)
+    const uint64_t rot = ((uint64_t)funnel(m_hi, m_lo, 15) << 32) | funnel(m_lo, m_hi, 15);
+    const uint64_t result = rot + s.s0;
+    b_lo ^= a_lo;
+    b_hi ^= a_hi;
+    // rotl(s0, 49) = halves swapped, then rotl 17
+    const uint32_t r49_hi = funnel(a_lo, a_hi, 15), r49_lo = funnel(a_hi, a_lo, 15);
+    // s1 << 21
+    const uint32_t sh_hi = funnel(b_hi, b_lo, 11), sh_lo = b_lo << 21;
+    const uint32_t n0_lo = r49_lo ^ b_lo ^ sh_lo, n0_hi = r49_hi ^ b_hi ^ sh_hi;
+    // rotl(s1, 28)
+    const uint32_t n1_hi = funnel(b_hi, b_lo, 4), n1_lo = funnel(b_lo, b_hi, 4);
+    s.s0 = ((uint64_t)n0_hi << 32) | n0_lo;
+    s.s1 = ((uint64_t)n1_hi << 32) | n1_lo;
+    return result;
+}
+#else
 DPOMP_HD uint64_t stream_next(Stream& s) {
     const uint64_t s0 = s.s0;
     uint64_t s1 = s.s1;
@@ -95,6 +123,7 @@ DPOMP_HD uint64_t stream_next(Stream& s) {
     s.s1 = rotl64(s1, 28);
     return result;
 }
+#endif
 
 // Top 52 bits -> u = (2k+1) 2^-53 in (0,1).  [1,2) mantissa trick: (d - 1) = k 2^-52 exactly,
 // and k 2^-52 + 2^-53 is representable, so this equals (double)(2k+1) * 2^-53 bit for bit.
@@ -118,7 +147,7 @@ DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
     const uint64_t ix = double_to_bits(x);
     const uint64_t tmp = ix - 0x3FE6000000000000ull;
     const int i = (int)((uint32_t)(tmp >> 45) & 127u);
-    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const int32_t k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // arithmetic shift of the high word == (int64)tmp >> 52
     const double z = bits_to_double(ix - (tmp & 0xFFF0000000000000ull));
     const double invc = T[i][0], logc = T[i][1];
     const double r = __builtin_fma(z, invc, -1.0);

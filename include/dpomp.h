@@ -152,6 +152,11 @@ int dpomp_set_stream(dpomp_handle* h, void* hip_stream);
 /* rs_type as in get_particle_filter_lpdf (DPOMP_RS_*; default systematic). */
 int dpomp_set_resampler(dpomp_handle* h, int rs_type);
 
+/* Tuning: particles per lane of the propagation kernel.  0 (default) = choose by launch size;
+ * 1 = one particle per lane; 2, 4 = workgroup-local queue with dynamic lane refill.
+ * Results do not depend on it. */
+int dpomp_set_particles_per_lane(dpomp_handle* h, int particles_per_lane);
+
 /* ---- the particle filter ------------------------------------------------------- */
 /* Full filter over observations 1..T for B independent parameter vectors
  * (estimate_likelihood for each theta[:,b]).  out_ll[B]; out_status[B] may be NULL. */

@@ -41,9 +41,12 @@ def test_device_numerics_match_oracle_bitwise(sis, orc):
     assert np.array_equal(ex, orc.dexp(-37.0 * x))
 
 
+@pytest.mark.parametrize("rpl", [1, 2, 4])
 @pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097])
-def test_sis_full_filter_matches_oracle(sis, orc, P):
+def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
+    """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane)."""
     theta = [0.003, 0.1]
+    sis.set_particles_per_lane(rpl)
     pop = sis.alloc_population(1, P)
     ll = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=11)
     ref = orc.pf_loglik(sis.desc, P, theta, seed=11)
@@ -52,6 +55,7 @@ def test_sis_full_filter_matches_oracle(sis, orc, P):
     assert sis.last_status[0] == ref.status
     _assert_ll(ll[0], ref.ll)
     assert ll[0] == ref.ll  # in practice exact
+    sis.set_particles_per_lane(0)
 
 
 def test_step_by_step_states_logw_and_offspring(sis, orc, dp):
@@ -127,13 +131,14 @@ def _synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99):
 
 
 @pytest.mark.parametrize("name,x0,fd,theta", CASES)
-@pytest.mark.parametrize("generic", [False, True])
-def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic):
+@pytest.mark.parametrize("generic,rpl", [(False, 1), (True, 1), (False, 4), (True, 2)])
+def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rpl):
     """Every catalogue model, compiled built-in evaluator and table-driven generic evaluator,
     equals the oracle (which only knows the generic table)."""
     model = dp.generate_model(name, x0, freq_dep=fd)
     y = _synthetic_data(dp, orc, model, theta)
     pf = dp.ParticleFilter(model, y, force_generic=generic)
+    pf.set_particles_per_lane(rpl)
     P = 777
     pop = pf.alloc_population(1, P)
     ll = pf.partial_log_likelihood(pop, theta, 1, len(y), seed=42)
@@ -166,6 +171,7 @@ def test_event_cap_flags_and_zeroes_the_weight(dp, orc, pooley):
     model = dp.generate_model("SIS", [100, 1])
     model.max_events_per_interval = 150  # intervals 2..5 need ~270 events per particle
     pf = dp.ParticleFilter(model, pooley)
+    pf.set_particles_per_lane(4)
     ll = pf.loglik([0.003, 0.1], 512, seed=2)
     ref = orc.pf_loglik(pf.desc, 512, [0.003, 0.1], seed=2)
     assert pf.last_status[0] & dp.ST_EVENT_CAP and ref.status & dp.ST_EVENT_CAP
@@ -242,3 +248,49 @@ def test_full_size_pooley_2pow20(sis, dp):
     # the same call twice gives the same bits; one call over 1..T equals the increments
     full = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=2026)[0]
     assert abs(full - sum(lls)) < 1e-12
+
+
+@pytest.mark.parametrize("pattern", ["low_weight_run", "alternating", "single_survivor"])
+def test_resampling_with_crafted_weights(dp, orc, make_obs, pattern):
+    """Uploaded populations with engineered weights: a long run of zero-weight parents (the output
+    window of one workgroup then spans more parent tiles than it stages in LDS -> fallback search),
+    alternating zero/non-zero parents, and a single surviving particle."""
+    model = dp.generate_model("SIS", [100, 1])
+    y = make_obs([1.0, 1.0 + 1e-9, 2.0], [[0, 50], [0, 50], [0, 50]])
+    pf = dp.ParticleFilter(model, y)
+    P = 20000
+    I = np.full(P, 50, dtype=np.int64)
+    if pattern == "low_weight_run":
+        I[1:9000] = 0          # > 8 tiles of parents with weight exp(-2500/8) -> 0 in fixed point
+        I[9000:9100] = 47      # a few light ones
+    elif pattern == "alternating":
+        I[::2] = 0
+        I[1::6] = 52
+    else:
+        I[:] = 0
+        I[12345] = 50
+    start = np.stack([101 - I, I], axis=1)
+    pop = pf.alloc_population(1, P)
+    pop.upload(0, start)
+    theta = [1e-7, 1e-7]  # essentially no events in the 1e-9 interval
+    ll = pf.partial_log_likelihood(pop, theta, 2, 2, seed=31)
+    ref_pop = start.copy()
+    ref = orc.pf_partial(pf.desc, ref_pop, theta, 2, 2, seed=31, trace=True)
+    assert np.array_equal(pop.debug(dp.DBG_OFFSPRING_END).astype(np.int64), ref.offspring_end)
+    assert np.array_equal(pop.download(0), ref_pop)
+    assert ll[0] == ref.ll
+    if pattern == "single_survivor":
+        assert np.all(pop.download(0)[:, 1] == 50)
+    pf.close()
+
+
+def test_many_segments_small_filters(dp, orc, pooley):
+    """SMC^2 shape: many segments, few particles each (B = 300, P = 200, the reference's default npf)."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    rng = np.random.default_rng(1)
+    B = 300
+    theta = np.stack([rng.uniform(0.002, 0.004, B), rng.uniform(0.05, 0.2, B)])
+    got = pf.loglik(theta, 200, seed=5)
+    for b in rng.integers(0, B, 12):
+        assert got[b] == orc.pf_loglik(pf.desc, 200, theta[:, b], seed=5, seg=int(b)).ll
+    pf.close()
