@@ -26,15 +26,18 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 
 typedef void (*PropFn)(PropArgs);
 
+constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 constexpr int kGatherLdsMaxTiles = 8192;  // k_gather: tile boundaries (4 B each) + 16 KB window must fit LDS
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
 // particles per lane (chosen by how many particles the launch has, see pick_prop).
 struct PropSet {
-    PropFn fn1, q2, q4;
+    PropFn fn1, q2, q4, c16, c32;
 };
-#define DPOMP_PROPSET(...) {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>}
+#define DPOMP_PROPSET(...)                                                                     \
+    {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>, \
+     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>}
 
 struct PropEntry {
     int builtin, S, E;
@@ -68,7 +71,7 @@ PropSet generic_set(int S, int E) {
     DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
     DPOMP_G(8, 4) DPOMP_G(8, 8)
 #undef DPOMP_G
-    return PropSet{nullptr, nullptr, nullptr};
+    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 struct KernelStat {
@@ -92,9 +95,10 @@ struct dpomp_handle {
     std::vector<double> obs_time;
     std::vector<int64_t> obs_id;
     std::vector<long long> ysum;
-    PropSet prop{nullptr, nullptr, nullptr};
+    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
-    int force_rpl = 0;  // 0 = choose by launch size; 1, 2, 4 = force (tests, tuning)
+    int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
+                        // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
     bool profiling = false;
     KernelStat stats[KID_COUNT];
@@ -336,12 +340,9 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
             int rpl = h->force_rpl;
-            if (rpl != 1 && rpl != 2 && rpl != 4) {
-                const int64_t waves1 = B * ((p->P + 63) / 64);
-                rpl = waves1 >= 16384 ? 4 : (waves1 >= 8192 ? 2 : 1);
-            }
-            PropFn fn = rpl == 4 ? h->prop.q4 : (rpl == 2 ? h->prop.q2 : h->prop.fn1);
-            const int64_t chunk = (int64_t)kBlock * rpl;
+            if (rpl == 0) rpl = kDefaultPropVariant;
+            PropFn fn = rpl == 4 ? h->prop.q4 : rpl == 2 ? h->prop.q2 : rpl == 16 ? h->prop.c16 : rpl == 32 ? h->prop.c32 : h->prop.fn1;
+            const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
             hipLaunchKernelGGL(fn, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, 0, st, a);
         }
@@ -518,9 +519,10 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type) {
     return DPOMP_OK;
 }
 
-int dpomp_set_particles_per_lane(dpomp_handle* h, int rpl) {
+int dpomp_set_propagate_variant(dpomp_handle* h, int rpl) {
     if (!h) return DPOMP_EINVAL;
-    if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4) return fail(h, DPOMP_EINVAL, "particles_per_lane must be 0, 1, 2 or 4");
+    if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4 && rpl != 16 && rpl != 32)
+        return fail(h, DPOMP_EINVAL, "propagate variant must be 0, 1, 2, 4, 16 or 32");
     h->force_rpl = rpl;
     return DPOMP_OK;
 }

@@ -474,6 +474,178 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     }
 }
 
+// ---- k_propagate_c: one particle per lane + workgroup-level compaction ------------------------------
+// Lanes whose particle has reached t_max idle until the slowest lane of the wave is done, and a
+// wave with 5 live lanes costs the VALU as much as one with 64.  Every CHK events the workgroup
+// counts its live lanes (ballot + 4 LDS words + one barrier); when they fit in fewer waves than
+// are still running, the live contexts (state, stream, clock, event count, particle slot) are
+// packed through LDS into the lowest lanes of the workgroup and the emptied waves only keep
+// meeting the barrier.  Finished particles park their final state in an LDS tile, and the
+// epilogue (weights, coalesced write-back, reductions) runs at full occupancy.  The arithmetic of
+// a particle does not depend on the lane it runs in, so results stay bit-identical.
+template <class R, int CHK>
+__global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
+    constexpr int S = R::S, E = R::E;
+    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    __shared__ double s_log[128][2];
+    __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
+    __shared__ int32_t s_cnt[kBlock];     // executed events, bit 31 = event cap
+    __shared__ int32_t c_x[S][kBlock];    // compaction staging
+    __shared__ uint4 c_rng[kBlock];
+    __shared__ double c_time[kBlock];
+    __shared__ int2 c_nc[kBlock];
+    __shared__ int s_wcnt[2][kBlock / 64];
+    __shared__ double s_max[kBlock / 64];
+    __shared__ unsigned long long s_ev[kBlock / 64];
+    __shared__ int s_cap[kBlock / 64];
+
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = p < a.P;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int s_real = R::kGeneric ? a.m.S : S;
+    int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
+    const double* th = a.theta + (int64_t)b * a.m.K;
+
+    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+
+    int x[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
+    double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
+    const double tmax = a.t_max;
+    Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
+    const int e_real = R::kGeneric ? a.m.E : E;
+    const int cap = a.m.cap;
+    int n = 0, cur = threadIdx.x;
+    bool active = valid;  // particle still running
+    bool parked = !valid; // final state already parked in s_res
+    bool capped = false;
+    __syncthreads();
+
+    for (int round = 0;; ++round) {
+        for (int it = 0; it < CHK; ++it) {  // wave-uniform trip count; the body is the static kernel's
+            if (!__any(active)) break;
+            if (active) {
+                double cum[E];
+                R::rates(a.m, th, x, cum);
+#pragma unroll
+                for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+                const double tot = cum[E - 1];
+                if (tot == 0.0) {
+                    active = false;
+                } else {
+                    const double u1 = u01(stream_next(rng));
+                    time = time - dlog_tab(u1, s_log) / tot;
+                    if (time > tmax) {
+                        active = false;
+                    } else {
+                        const double etc = u01(stream_next(rng)) * tot;
+                        TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+                        for (int i = E - 2; i >= 0; --i) {
+                            const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                            if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
+                        }
+#pragma unroll
+                        for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+                        if (++n >= cap) {
+                            capped = true;
+                            active = false;
+                        }
+                    }
+                }
+            }
+        }
+        if (!active && !parked) {  // once per particle, outside the hot loop
+#pragma unroll
+            for (int s = 0; s < S; ++s) s_res[s][cur] = x[s];
+            s_cnt[cur] = n | (capped ? (int)0x80000000 : 0);
+            parked = true;
+        }
+        const unsigned long long bal = __ballot(active);
+        if (lane == 0) s_wcnt[round & 1][wid] = __popcll(bal);
+        __syncthreads();
+        const int c0 = s_wcnt[round & 1][0], c1 = s_wcnt[round & 1][1], c2 = s_wcnt[round & 1][2],
+                  c3 = s_wcnt[round & 1][3];
+        const int total = (c0 + c1) + (c2 + c3);
+        if (total == 0) break;
+        const int waves_now = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+        if (((total + 63) >> 6) < waves_now) {  // workgroup-uniform
+            if (active) {
+                const int rank = (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0) +
+                                 __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int s = 0; s < S; ++s) c_x[s][rank] = x[s];
+                c_rng[rank] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1,
+                                         (uint32_t)(rng.s1 >> 32));
+                c_time[rank] = time;
+                c_nc[rank] = make_int2(n, cur);
+            }
+            __syncthreads();
+            active = (int)threadIdx.x < total;
+            parked = !active;  // every lane without a live context has already parked (or never had) its particle
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] = c_x[s][threadIdx.x];
+                const uint4 r4 = c_rng[threadIdx.x];
+                rng.s0 = (uint64_t)r4.x | ((uint64_t)r4.y << 32);
+                rng.s1 = (uint64_t)r4.z | ((uint64_t)r4.w << 32);
+                time = c_time[threadIdx.x];
+                const int2 nc = c_nc[threadIdx.x];
+                n = nc.x;
+                cur = nc.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    double g = -__builtin_inf();
+    unsigned long long ev = 0;
+    capped = false;
+    if (valid) {
+        int xs = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int v = s_res[s][threadIdx.x];
+            if (s < s_real) st[(int64_t)s * a.Pp + p] = v;
+            if (a.m.obs_state_mask & (1u << s)) xs += v;
+        }
+        const int c = s_cnt[threadIdx.x];
+        ev = (unsigned long long)(c & 0x7FFFFFFF);
+        capped = c < 0;
+        if (a.want_weight) {
+            const long long d = a.ysum - (long long)xs;
+            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
+            a.logw[(int64_t)b * a.Pp + p] = g;
+        }
+    }
+    const double wm = wave_max(g);
+    const unsigned long long wev = wave_sum(ev);
+    const int wcap = __any(capped);
+    if (lane == 0) {
+        s_max[wid] = wm;
+        s_ev[wid] = wev;
+        s_cap[wid] = wcap;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bm = s_max[0];
+        unsigned long long be = s_ev[0];
+        int bc = s_cap[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) {
+            bm = fmax(bm, s_max[w]);
+            be += s_ev[w];
+            bc |= s_cap[w];
+        }
+        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (be) atomicAdd(a.events, be);
+        if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+    }
+}
+
 // ---- weights -----------------------------------------------------------------------------------
 struct WeightArgs {
     const double* logw;                 // [B][Pp]

@@ -122,9 +122,9 @@ class ParticleFilter:
         """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         self._check(self._lib.dpomp_set_stream(self._h, C.c_void_p(raw_stream or 0)))
 
-    def set_particles_per_lane(self, rpl: int):
-        """Propagation-kernel tuning (0 = auto, 1, 2, 4); never changes a result."""
-        self._check(self._lib.dpomp_set_particles_per_lane(self._h, int(rpl)))
+    def set_propagate_variant(self, rpl: int):
+        """Propagation-kernel variant (0 default, 1 static, 2/4 LDS queue, 16/32 compaction); never changes a result."""
+        self._check(self._lib.dpomp_set_propagate_variant(self._h, int(rpl)))
 
     def _theta_matrix(self, theta) -> np.ndarray:
         th = np.asarray(theta, dtype=np.float64)

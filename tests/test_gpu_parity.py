@@ -41,12 +41,12 @@ def test_device_numerics_match_oracle_bitwise(sis, orc):
     assert np.array_equal(ex, orc.dexp(-37.0 * x))
 
 
-@pytest.mark.parametrize("rpl", [1, 2, 4])
+@pytest.mark.parametrize("rpl", [1, 2, 4, 16, 32])
 @pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097])
 def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
     """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane)."""
     theta = [0.003, 0.1]
-    sis.set_particles_per_lane(rpl)
+    sis.set_propagate_variant(rpl)
     pop = sis.alloc_population(1, P)
     ll = sis.partial_log_likelihood(pop, theta, 1, sis.n_obs, seed=11)
     ref = orc.pf_loglik(sis.desc, P, theta, seed=11)
@@ -55,7 +55,7 @@ def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
     assert sis.last_status[0] == ref.status
     _assert_ll(ll[0], ref.ll)
     assert ll[0] == ref.ll  # in practice exact
-    sis.set_particles_per_lane(0)
+    sis.set_propagate_variant(0)
 
 
 def test_step_by_step_states_logw_and_offspring(sis, orc, dp):
@@ -131,14 +131,14 @@ def _synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99):
 
 
 @pytest.mark.parametrize("name,x0,fd,theta", CASES)
-@pytest.mark.parametrize("generic,rpl", [(False, 1), (True, 1), (False, 4), (True, 2)])
+@pytest.mark.parametrize("generic,rpl", [(False, 1), (True, 1), (False, 4), (True, 2), (False, 16), (True, 32)])
 def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rpl):
     """Every catalogue model, compiled built-in evaluator and table-driven generic evaluator,
     equals the oracle (which only knows the generic table)."""
     model = dp.generate_model(name, x0, freq_dep=fd)
     y = _synthetic_data(dp, orc, model, theta)
     pf = dp.ParticleFilter(model, y, force_generic=generic)
-    pf.set_particles_per_lane(rpl)
+    pf.set_propagate_variant(rpl)
     P = 777
     pop = pf.alloc_population(1, P)
     ll = pf.partial_log_likelihood(pop, theta, 1, len(y), seed=42)
@@ -171,7 +171,7 @@ def test_event_cap_flags_and_zeroes_the_weight(dp, orc, pooley):
     model = dp.generate_model("SIS", [100, 1])
     model.max_events_per_interval = 150  # intervals 2..5 need ~270 events per particle
     pf = dp.ParticleFilter(model, pooley)
-    pf.set_particles_per_lane(4)
+    pf.set_propagate_variant(4)
     ll = pf.loglik([0.003, 0.1], 512, seed=2)
     ref = orc.pf_loglik(pf.desc, 512, [0.003, 0.1], seed=2)
     assert pf.last_status[0] & dp.ST_EVENT_CAP and ref.status & dp.ST_EVENT_CAP
