@@ -8,6 +8,9 @@ from ._abi import (DpompLibraryMissing, ST_EVENT_CAP, ST_ZERO_WEIGHT, RS_SYSTEMA
 from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, RateFunction, RateTerm,
                     UniformProductPrior, dmy_obs_fn, generate_custom_model, generate_model,
                     generate_weak_prior, get_observations, partial_gaussian_obs_model)
+from .smc2 import (ImportanceSample, compute_ess, compute_is_mu_covar, rs_systematic, run_ibis_analysis, run_pibis,
+                   run_smc2_analysis)
+from . import parallel  # noqa: F401
 from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population,
                               get_particle_filter_lpdf)
 

@@ -580,6 +580,31 @@ int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
     return DPOMP_OK;
 }
 
+int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const int64_t* take) {
+    if (!h) return DPOMP_EINVAL;
+    if (!dst || !src || !take || dst == src) return fail(h, DPOMP_EINVAL, "dst/src/take invalid");
+    if (dst->P != src->P || dst->S != src->S) return fail(h, DPOMP_EINVAL, "populations differ in shape");
+    bool any = false;
+    for (int64_t b = 0; b < dst->B; ++b) {
+        if (take[b] >= src->B) return fail(h, DPOMP_EINVAL, "take[%lld]=%lld out of range", (long long)b, (long long)take[b]);
+        any |= take[b] >= 0;
+    }
+    if (!any) return DPOMP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(dst->ancestors, take, (size_t)dst->B * 8, hipMemcpyHostToDevice, h->stream));
+    const int64_t seg_ints = (int64_t)dst->S * dst->Pp;
+    {
+        ScopedTiming tm(h, KID_COPYSEG);
+        hipLaunchKernelGGL(k_take_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)dst->B), dim3(kBlock), 0, h->stream,
+                           (const int32_t*)src->state[src->cur], dst->state[dst->cur], (const int64_t*)dst->ancestors, seg_ints);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    collect_timings(h);
+    dst->initialised = true;
+    return DPOMP_OK;
+}
+
 int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* p, int64_t b, int64_t* out) {
     if (!h) return DPOMP_EINVAL;
     if (!p || !out || b < 0 || b >= p->B) return fail(h, DPOMP_EINVAL, "bad pop/out/b");

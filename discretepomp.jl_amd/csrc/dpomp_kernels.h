@@ -901,6 +901,16 @@ __global__ __launch_bounds__(kBlock) void k_copy_segments(const int32_t* src, in
         *reinterpret_cast<const int4*>(src + a * seg_ints + i0);
 }
 
+// ---- k_take_segments: dst[b] <- src[take[b]] where take[b] >= 0   (hmm_ibis.jl:109) -----------------
+__global__ __launch_bounds__(kBlock) void k_take_segments(const int32_t* src, int32_t* dst, const int64_t* take,
+                                                          int64_t seg_ints) {
+    const int64_t b = blockIdx.y;
+    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kItems;
+    const int64_t t = take[b];
+    if (t < 0 || i0 >= seg_ints) return;
+    *reinterpret_cast<int4*>(dst + b * seg_ints + i0) = *reinterpret_cast<const int4*>(src + t * seg_ints + i0);
+}
+
 // ---- k_selftest: device evaluation of the shared numerics ----------------------------------------
 __global__ void k_selftest(int64_t n, uint64_t seed, const double* x, double* out_u, double* out_log,
                            double* out_exp) {

@@ -77,6 +77,14 @@ class Population:
             raise ValueError("one ancestor per segment")
         self._pf._check(self._pf._lib.dpomp_pop_gather(self._pf._h, self._ptr, a.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    def take(self, other: "Population", take: Sequence[int]):
+        """``self[b] <- other[take[b]]`` where ``take[b] >= 0`` (accepted PMMH proposals,
+        src/hmm_ibis.jl:109)."""
+        t = np.ascontiguousarray(take, dtype=np.int64)
+        if t.shape != (self.B,):
+            raise ValueError("one entry per segment")
+        self._pf._check(self._pf._lib.dpomp_pop_take(self._pf._h, self._ptr, other._ptr, t.ctypes.data_as(C.POINTER(C.c_int64))))
+
     def debug(self, what: int, b: int = 0) -> np.ndarray:
         out = np.empty(self.P, dtype=np.float64 if what == _abi.DBG_LOGW else np.int32)
         self._pf._check(self._pf._lib.dpomp_debug_download(self._pf._h, self._ptr, what, b, out.ctypes.data_as(C.c_void_p)))

@@ -17,6 +17,7 @@
  *                           per-theta populations          src/hmm_ibis.jl:26-30
  *   dpomp_pf_partial     <- partial_log_likelihood!        src/hmm_particle_filter.jl:39-76
  *   dpomp_pop_gather     <- theta-level ancestor copy      src/hmm_ibis.jl:71-75
+ *   dpomp_pop_take       <- accepted PMMH proposal `pop[p] .= pop_f`   src/hmm_ibis.jl:109
  *   dpomp_pop_download   <- reading the caller-owned `pop::Array{Int64,2}` after the call
  *   dpomp_pop_upload     <- writing it before the call
  *   dpomp_simulate       <- gillespie_sim (final states at each observation time only)
@@ -177,6 +178,10 @@ int dpomp_pf_partial(dpomp_handle* h, dpomp_pop* pop, const double* theta, int32
 
 /* pop[b] <- pop[ancestors[b]] for all b (0-based ancestors), as hmm_ibis.jl:71-75. */
 int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* pop, const int64_t* ancestors);
+/* dst[b] <- src[take[b]] for every b with take[b] >= 0 (segments with take[b] < 0 keep their
+ * population): installs the populations of accepted proposals, hmm_ibis.jl:109.  dst and src are
+ * distinct handles of the same filter with equal P. */
+int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const int64_t* take);
 /* Segment b as a P x S column-major Int64 matrix. */
 int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* pop, int64_t b, int64_t* out);
 int dpomp_pop_upload(dpomp_handle* h, dpomp_pop* pop, int64_t b, const int64_t* in);

@@ -67,3 +67,18 @@ if __name__ == "__main__":
     for th in [(0.003, 0.1), (0.0032, 0.1), (0.0025, 0.08), (0.004, 0.15)]:
         ll, incs = exact_sis_loglik(th, [100, 1], POOLEY_TIMES, POOLEY_CASES)
         print(th, f"{ll:.10f}", [f"{v:.6f}" for v in incs])
+
+
+def exact_evidence(lower, upper, x0=(100, 1), times=POOLEY_TIMES, cases=POOLEY_CASES, n=40, sigma=2.0):
+    """-ln p(y) and posterior means under a uniform prior on [lower, upper] (2-D), by midpoint quadrature
+    of the exact likelihood on an n x n grid (20.1676, beta 0.003246, gamma 0.10832 for
+    U(0,0.01) x U(0,0.5), the prior of test/runtests.jl:29)."""
+    import numpy as _np
+    bs = lower[0] + (upper[0] - lower[0]) * (_np.arange(n) + 0.5) / n
+    gs = lower[1] + (upper[1] - lower[1]) * (_np.arange(n) + 0.5) / n
+    ll = _np.array([[exact_sis_loglik((b, g), x0, times, cases, sigma)[0] for g in gs] for b in bs])
+    m = ll.max()
+    w = _np.exp(ll - m)
+    z = w.mean()
+    return {"neg_log_evidence": float(-(m + math.log(z))), "beta_mean": float((w * bs[:, None]).sum() / w.sum()),
+            "gamma_mean": float((w * gs[None, :]).sum() / w.sum())}

@@ -58,6 +58,14 @@ def main():
     for theta in [(0.003, 0.1), (0.0032, 0.1), (0.0025, 0.08), (0.004, 0.15)]:
         ll, incs = exact_sis.exact_sis_loglik(theta, [100, 1], exact_sis.POOLEY_TIMES, exact_sis.POOLEY_CASES)
         out["exact_pooley_sis"][f"{theta[0]},{theta[1]}"] = {"ll": ll, "increments": incs}
+    # exact evidence under the prior of test/runtests.jl:29 (100 x 100 quadrature, ~5 minutes): kept from the
+    # previous file unless --evidence is given
+    key = "exact_pooley_sis_evidence_u001_u05"
+    path = os.path.join(HERE, "pf_golden.json")
+    if "--evidence" in sys.argv or not os.path.exists(path) or key not in json.load(open(path)):
+        out[key] = exact_sis.exact_evidence((0, 0), (0.01, 0.5), n=100)
+    else:
+        out[key] = json.load(open(path))[key]
     with open(os.path.join(HERE, "pf_golden.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote pf_golden.json:", [c["name"] for c in out["cases"]])

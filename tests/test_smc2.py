@@ -1,0 +1,133 @@
+"""SMC^2 host driver (run_pibis, src/hmm_ibis.jl:12-135).  The reference pins it only through a seed-1
+value of -ln evidence (19.98, test/runtests.jl:48-52); the exact value under that prior is 20.1676."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EXACT = json.load(open(os.path.join(GOLDEN, "pf_golden.json")))["exact_pooley_sis_evidence_u001_u05"]
+
+
+class OraclePop:
+    def __init__(self, B, P, S):
+        self.B, self.P = B, P
+        self.pops = [np.zeros((P, S), dtype=np.int64) for _ in range(B)]
+
+    def gather(self, anc):
+        self.pops = [self.pops[a].copy() for a in anc]
+
+    def take(self, other, take):
+        for b, t in enumerate(take):
+            if t >= 0:
+                self.pops[b] = other.pops[t].copy()
+
+    def close(self):
+        pass
+
+
+class OracleBank:
+    """Same surface as ParticleFilter, computed by the CPU oracle (tests only)."""
+
+    def __init__(self, dp, orc, model, obs):
+        self.orc, self.desc = orc, dp.ModelDescriptor(model, obs)
+        self.n_obs, self.n_states = self.desc.n_obs, self.desc.n_states
+
+    def alloc_population(self, B, P):
+        return OraclePop(B, P, self.n_states)
+
+    def partial_log_likelihood(self, pop, theta, ymin, ymax, seed=1, seg_base=0):
+        theta = np.asarray(theta)
+        return np.array([self.orc.pf_partial(self.desc, pop.pops[b], theta[:, b], ymin, ymax, seed=seed, seg=seg_base + b).ll
+                         for b in range(pop.B)])
+
+
+def test_theta_level_helpers(dp):
+    rng = np.random.default_rng(0)
+    w = np.array([0.0, 3.0, 0.0, 1.0])
+    idx = dp.rs_systematic(w, rng)
+    assert list(idx) in ([1, 1, 1, 3], [1, 1, 3, 3]) and np.all(np.diff(idx) >= 0)
+    counts = np.zeros(4)
+    for _ in range(4000):
+        counts += np.bincount(dp.rs_systematic(w, rng), minlength=4)
+    assert np.allclose(counts / counts.sum(), w / w.sum(), atol=0.01)
+    theta = np.array([[1.0, 2.0, 4.0], [0.0, 1.0, 0.0]])
+    mu, cv = dp.compute_is_mu_covar(theta, np.array([1.0, 1.0, 2.0]))
+    assert np.allclose(mu, [2.75, 0.25]) and np.isclose(cv[0, 0], (1.75 ** 2 + 0.75 ** 2 + 2 * 1.25 ** 2) / 4)
+    assert np.isclose(cv[0, 1], cv[1, 0]) and dp.compute_ess(np.ones(10)) == 10.0
+
+
+REFERENCE_SEED1_BME = 19.98  # test/runtests.jl:51 -- the reference's own pinned value of -ln evidence
+
+
+def test_run_pibis_reproduces_the_reference_value(dp, orc, pooley):
+    """Algorithm as written in the reference (independent proposals, no proposal-density correction):
+    -ln evidence lands on the reference's pinned 19.98, not on the exact 20.17 -- the bias is the reference's."""
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    vals = []
+    for s in range(3):
+        rng = np.random.default_rng(40 + s)
+        out = dp.run_pibis(OracleBank(dp, orc, model, pooley), prior, prior.rand(rng, 1000), 0.3, True, 1.002, 100, seed=s,
+                           rng=rng, verbose=False)
+        assert out.n_resample >= 1 and 0.3 < out.acceptance_rate < 0.9 and out.theta.shape == (2, 1000)
+        vals.append(out.bme[0])
+    assert abs(np.mean(vals) - REFERENCE_SEED1_BME) < 0.15, vals   # sd over seeds ~0.09 at this size
+    assert np.mean(vals) < EXACT["neg_log_evidence"] - 0.05         # and visibly below the exact value
+
+
+@pytest.mark.parametrize("ind_prop", [True, False])
+def test_run_pibis_valid_kernels_reach_the_exact_evidence(dp, orc, pooley, ind_prop):
+    """With a valid PMMH kernel (independent proposals WITH the q-ratio, or symmetric random-walk proposals)
+    the same driver converges on the exact evidence and posterior mean."""
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    bme, beta = [], []
+    for s in range(3):
+        rng = np.random.default_rng(70 + s)
+        out = dp.run_pibis(OracleBank(dp, orc, model, pooley), prior, prior.rand(rng, 1000), 0.3, ind_prop, 1.002, 100,
+                           seed=s, rng=rng, verbose=False, proposal_correction=True)
+        bme.append(out.bme[0])
+        beta.append(out.mu[0])
+    assert abs(np.mean(bme) - EXACT["neg_log_evidence"]) < 0.2, bme
+    assert abs(np.mean(beta) - EXACT["beta_mean"]) < 0.06 * EXACT["beta_mean"], beta
+
+
+def test_exact_evidence_quadrature_is_stable():
+    from oracle import exact_sis
+    coarse = exact_sis.exact_evidence((0, 0), (0.01, 0.5), n=20)
+    assert abs(coarse["neg_log_evidence"] - EXACT["neg_log_evidence"]) < 0.05
+    assert abs(EXACT["neg_log_evidence"] - 20.1676) < 1e-3 and abs(EXACT["beta_mean"] - 0.003246) < 1e-6
+
+
+@pytest.mark.gpu
+def test_smc2_reference_configuration_on_gpu(dp, pooley):
+    """The reference's own smc2 testset (test/runtests.jl:48-52): 4000 theta-particles x 200 state particles,
+    prior U(0,0.01) x U(0,0.5).  Reference seed-1 value 19.98; exact 20.1676."""
+    model = dp.generate_model("SIS", [100, 1])
+    model.prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    # Measured over 20 seeds on MI355X (tools/smc2_spread.py): as written 20.07 +- 0.07, corrected 20.177 +- 0.064.
+    runs = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False) for s in range(1, 9)]
+    bme = np.array([o.bme[0] for o in runs])
+    assert runs[0].theta.shape == (2, 4000)
+    assert abs(bme.mean() - REFERENCE_SEED1_BME) < 0.2, bme     # reference: bme[1] ~ 19.98 (Julia index 1), one seed
+    assert bme.min() < REFERENCE_SEED1_BME + 0.07                # 19.98 lies inside our seed-to-seed scatter
+    fixed = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False, proposal_correction=True) for s in range(1, 9)]
+    assert abs(np.mean([o.bme[0] for o in fixed]) - EXACT["neg_log_evidence"]) < 0.08
+    assert abs(np.mean([o.mu[0] for o in fixed]) - EXACT["beta_mean"]) < 0.02 * EXACT["beta_mean"]
+    assert abs(np.mean([o.mu[1] for o in fixed]) - EXACT["gamma_mean"]) < 0.03 * EXACT["gamma_mean"]
+
+
+@pytest.mark.gpu
+def test_smc2_gpu_equals_oracle_bank_at_same_seeds(dp, orc, pooley):
+    """Same driver, same seeds: the GPU bank and the oracle bank must walk the identical path."""
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    theta0 = prior.rand(np.random.default_rng(5), 64)
+    a = dp.run_pibis(OracleBank(dp, orc, model, pooley), prior, theta0, 0.3, True, 1.002, 128, seed=9,
+                     rng=np.random.default_rng(11), verbose=False)
+    pf = dp.ParticleFilter(model, pooley)
+    b = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 128, seed=9, rng=np.random.default_rng(11), verbose=False)
+    assert np.array_equal(a.bme, b.bme) and np.array_equal(a.theta, b.theta) and np.array_equal(a.weight, b.weight)
+    pf.close()
