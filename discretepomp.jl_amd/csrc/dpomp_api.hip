@@ -27,6 +27,7 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 typedef void (*PropFn)(PropArgs);
 
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
+constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 constexpr int kGatherLdsMaxTiles = 8192;  // k_gather: tile boundaries (4 B each) + 16 KB window must fit LDS
 
@@ -121,6 +122,8 @@ struct dpomp_pop {
     unsigned long long* blocksum = nullptr;
     unsigned long long* blockprefix = nullptr;
     int32_t* tile_end = nullptr;           // [B][nblk]
+    double* posw = nullptr;                // [B][Pp]   (allocated on first use of resampler 2 / 3)
+    double* tile_end_pos = nullptr;        // [B][nblk]
     unsigned long long* segmax = nullptr;  // [T][B]
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]
@@ -236,6 +239,8 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->blocksum);
     (void)hipFree(p->blockprefix);
     (void)hipFree(p->tile_end);
+    (void)hipFree(p->posw);
+    (void)hipFree(p->tile_end_pos);
     (void)hipFree(p->segmax);
     (void)hipFree(p->wtot);
     (void)hipFree(p->ll);
@@ -295,8 +300,14 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (ymin < 1 || ymax > T || ymin > ymax) return fail(h, DPOMP_EINVAL, "ymin=%d ymax=%d out of 1..%d", ymin, ymax, T);
     if (ymin > 1 && !p->initialised) return fail(h, DPOMP_ESTATE, "ymin=%d on a population that was never initialised (call with ymin=1 or upload first)", ymin);
     if (seg_base < 0 || seg_base + p->B > 0xFFFFFFFFll) return fail(h, DPOMP_EINVAL, "seg_base out of range");
-    if (h->rs_type != DPOMP_RS_SYSTEMATIC) return fail(h, DPOMP_EINVAL, "resampler %d is not implemented yet (only systematic)", h->rs_type);
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
+        if (p->nblk > kGatherPosMaxTiles) return fail(h, DPOMP_EINVAL, "resampler %d supports at most %d particles per filter", h->rs_type, kGatherPosMaxTiles * kTile);
+        if (!p->posw) {
+            HIPCHK(h, hipMalloc((void**)&p->posw, (size_t)p->B * p->Pp * 8));
+            HIPCHK(h, hipMalloc((void**)&p->tile_end_pos, (size_t)p->B * p->nblk * 8));
+        }
+    }
     hipStream_t st = h->stream;
     const int64_t B = p->B;
     const dim3 block(kBlock);
@@ -361,6 +372,9 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.status = p->status;
             w.offs = p->offs;
             w.tile_end = p->tile_end;
+            w.posw = p->posw;
+            w.tile_end_pos = p->tile_end_pos;
+            w.rs_type = h->rs_type;
             w.Pp = p->Pp;
             w.P = (int32_t)p->P;
             w.nblk = p->nblk;
@@ -383,6 +397,26 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                     ScopedTiming tm(h, KID_OFFSETS);  // fused: also the tile-sum scan and the :60 update
                     if (fused) hipLaunchKernelGGL(k_offsets<true>, grid_tiles, block, 0, st, w);
                     else hipLaunchKernelGGL(k_offsets<false>, grid_tiles, block, 0, st, w);
+                }
+                if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
+                    GatherPosArgs gp;
+                    gp.src = p->state[p->cur];
+                    gp.dst = p->state[p->cur ^ 1];
+                    gp.posw = p->posw;
+                    gp.tile_end_pos = p->tile_end_pos;
+                    gp.Pp = p->Pp;
+                    gp.P = (int32_t)p->P;
+                    gp.S = p->S;
+                    gp.nblk = p->nblk;
+                    gp.rs_type = h->rs_type;
+                    gp.obs_k = (uint32_t)k;
+                    gp.seg_base = (uint32_t)seg_base;
+                    gp.seed = seed;
+                    ScopedTiming tm(h, KID_GATHER);
+                    hipLaunchKernelGGL(k_gather_pos, grid_tiles, block, (size_t)p->nblk * 8, st, gp);
+                    p->cur ^= 1;
+                    t_prev = h->obs_time[k];
+                    continue;
                 }
                 GatherArgs g;
                 g.src = p->state[p->cur];

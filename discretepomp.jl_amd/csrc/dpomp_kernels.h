@@ -657,7 +657,10 @@ struct WeightArgs {
     uint32_t* status;                   // [B]
     int32_t* offs;                      // [B][Pp]
     int32_t* tile_end;                  // [B][nblk] N of the last particle of each 1024-tile
+    double* posw;                       // [B][Pp]   pos_j = c_j / W * P (stratified / multinomial resamplers)
+    double* tile_end_pos;               // [B][nblk] pos of the last particle of each tile
     int64_t Pp;
+    int32_t rs_type;                    // DPOMP_RS_*
     int32_t P, nblk, sh;
     uint32_t obs_k, seg_base;
     uint64_t seed;
@@ -783,13 +786,27 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
 
     Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
     const double r = u01(stream_next(rs));  // rand() of hmm_pf_resample.jl:27
-    int n[kItems];
-#pragma unroll
-    for (int q = 0; q < kItems; ++q)
-        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
-    *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
-    if (threadIdx.x == kBlock - 1) a.tile_end[(int64_t)b * a.nblk + blk] = n[kItems - 1];
+    if (a.rs_type == 1) {
+        int n[kItems];
+#pragma unroll
+        for (int q = 0; q < kItems; ++q)
+            n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
+        *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
+        if (threadIdx.x == kBlock - 1) a.tile_end[(int64_t)b * a.nblk + blk] = n[kItems - 1];
+    } else {
+        // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
+        // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
+        const double Wd = u64_to_double(W);
+        double ps[kItems];
+#pragma unroll
+        for (int q = 0; q < kItems; ++q)
+            ps[q] = (W == 0) ? (double)a.P : (u64_to_double(base + c[q]) / Wd) * (double)a.P;
+        double* dst = a.posw + (int64_t)b * a.Pp + i0;
+        *reinterpret_cast<double2*>(dst) = make_double2(ps[0], ps[1]);
+        *reinterpret_cast<double2*>(dst + 2) = make_double2(ps[2], ps[3]);
+        if (threadIdx.x == kBlock - 1) a.tile_end_pos[(int64_t)b * a.nblk + blk] = ps[kItems - 1];
+    }
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------
@@ -881,6 +898,61 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
             } else {
                 j[q] = 0;
             }
+        }
+    }
+    for (int s = 0; s < a.S; ++s) {
+        const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
+        const int4 v = make_int4(src[j[0]], src[j[1]], src[j[2]], src[j[3]]);
+        *reinterpret_cast<int4*>(a.dst + ((int64_t)b * a.S + s) * a.Pp + i0) = v;
+    }
+}
+
+// ---- k_gather_pos: stratified (rsp_stratified hmm_pf_resample.jl:46-63) and multinomial (:5-20) --------
+// Slot i draws one uniform from its own stream (seed, segment, i, observation, DOMAIN_RESAMPLE_PARTICLE);
+// threshold t_i = i + u_i (stratified: one point per stratum) or P u_i (multinomial: i.i.d. points);
+// ancestor = first j with pos_j > t_i: tile through the tile_end_pos array in LDS, then 10 steps in L2.
+struct GatherPosArgs {
+    const int32_t* src;
+    int32_t* dst;
+    const double* posw;
+    const double* tile_end_pos;
+    int64_t Pp;
+    int32_t P, S, nblk, rs_type;
+    uint32_t obs_k, seg_base;
+    uint64_t seed;
+};
+
+template <class Ptr>
+__device__ __forceinline__ int first_greater_d(Ptr v, int n, double t) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (v[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_gather_pos(GatherPosArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double s_tep[];  // [nblk]
+    const int b = blockIdx.y;
+    const int64_t i0 = (int64_t)blockIdx.x * kTile + threadIdx.x * kItems;
+    const double* pos = a.posw + (int64_t)b * a.Pp;
+    const double* TE = a.tile_end_pos + (int64_t)b * a.nblk;
+    for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_tep[t] = TE[t];
+    __syncthreads();
+    int j[kItems];
+#pragma unroll
+    for (int q = 0; q < kItems; ++q) {
+        const int64_t i = i0 + q;
+        if (i < a.P) {
+            Stream ps = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)i, a.obs_k, DOMAIN_RESAMPLE_PARTICLE);
+            const double u = u01(stream_next(ps));
+            const double thr = (a.rs_type == 2) ? (double)i + u : (double)a.P * u;
+            const int t = first_greater_d(s_tep, a.nblk, thr);
+            const int within = first_greater_d(pos + (int64_t)t * kTile, kTile, thr);
+            j[q] = min(t * kTile + within, a.P - 1);
+        } else {
+            j[q] = 0;
         }
     }
     for (int s = 0; s < a.S; ++s) {

@@ -357,7 +357,7 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                    const orc_trace* tr) {
     const int S = d->n_states, T = d->n_obs;
     if (ymin < 1 || ymax > T || ymin > ymax || P < 1) return DPOMP_EINVAL;
-    if (rs_type != DPOMP_RS_SYSTEMATIC) return DPOMP_EINVAL;
+    if (rs_type < DPOMP_RS_SYSTEMATIC || rs_type > DPOMP_RS_MULTINOMIAL) return DPOMP_EINVAL;
     double t_prev;
     if (ymin == 1) { /* :41-45 */
         for (int64_t p = 0; p < P; ++p)
@@ -421,7 +421,43 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                 uint64_t rs[2];
                 orc_stream_init(seed, seg, 0u, (uint32_t)k, ORC_DOMAIN_RESAMPLE, rs);
                 double r = orc_u01(orc_stream_next(rs)); /* rand() hmm_pf_resample.jl:27 */
-                if (mode == ORC_MODE_FAITHFUL) {
+                if (rs_type != DPOMP_RS_SYSTEMATIC) {
+                    /* rsp_stratified (Kitagawa 1996, hmm_pf_resample.jl:46-63) and rsp_multinomial
+                     * (inverse CDF, :5-20).  Both throw as shipped (undefined `output` :55 / `weights` :10);
+                     * this follows their documented intent: stratified u_i = (rand_i + (i-1))/N * cw[end],
+                     * multinomial chs_i = rand_i * cw[end]; ancestor = first j whose cumulative weight
+                     * exceeds it.  One uniform per slot from its own stream. */
+                    for (int64_t i = 0; i < P; ++i) {
+                        uint64_t ps[2];
+                        orc_stream_init(seed, seg, (uint32_t)i, (uint32_t)k, ORC_DOMAIN_RESAMPLE_PARTICLE, ps);
+                        double ui = orc_u01(orc_stream_next(ps));
+                        int64_t j = 0;
+                        if (mode == ORC_MODE_FAITHFUL) {
+                            double thr = (rs_type == DPOMP_RS_STRATIFIED) ? (ui / (double)P + (double)i / (double)P) * cw[P - 1]
+                                                                          : ui * cw[P - 1];
+                            if (rs_type == DPOMP_RS_STRATIFIED) {
+                                while (thr > cw[j] && j < P - 1) ++j; /* :57 */
+                            } else {
+                                j = P - 1; /* new_p = length(weights) :11 */
+                                for (int64_t p2 = 0; p2 < P - 1; ++p2)
+                                    if (thr < cw[p2]) { j = p2; break; } /* :14 */
+                            }
+                        } else if (W > 0) {
+                            /* SPEC: pos_j = c_j/W * P; first j with pos_j > t_i, t_i = i + u_i or P u_i */
+                            double Wd = u64_to_double(W);
+                            double thr = (rs_type == DPOMP_RS_STRATIFIED) ? (double)i + ui : (double)P * ui;
+                            int64_t lo = 0, hi = P - 1;
+                            while (lo < hi) {
+                                int64_t mid = (lo + hi) >> 1;
+                                double pos = (u64_to_double(cint[mid]) / Wd) * (double)P;
+                                if (pos > thr) hi = mid; else lo = mid + 1;
+                            }
+                            j = lo;
+                        }
+                        for (int s2 = 0; s2 < S; ++s2) pop[i + P * s2] = old_p[j + P * s2];
+                        if (tr && tr->ancestors) tr->ancestors[i] = j;
+                    }
+                } else if (mode == ORC_MODE_FAITHFUL) {
                     /* rsp_systematic hmm_pf_resample.jl:24-42, verbatim in Float64 */
                     double u1 = r / (double)P; /* :27 */
                     int64_t j = 0;

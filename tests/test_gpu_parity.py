@@ -294,3 +294,27 @@ def test_many_segments_small_filters(dp, orc, pooley):
     for b in rng.integers(0, B, 12):
         assert got[b] == orc.pf_loglik(pf.desc, 200, theta[:, b], seed=5, seg=int(b)).ll
     pf.close()
+
+
+@pytest.mark.parametrize("rs_type", [2, 3])
+@pytest.mark.parametrize("P", [1, 777, 1024, 5000])
+def test_stratified_and_multinomial_resamplers_match_oracle(dp, orc, pooley, rs_type, P):
+    """rs_type 2 (stratified, Kitagawa) and 3 (multinomial): the reference's rsp_stratified /
+    rsp_multinomial throw as shipped; device == oracle SPEC on their documented intent."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=rs_type)
+    pop = pf.alloc_population(2, P)
+    theta = np.array([[0.003, 0.0028], [0.1, 0.09]])
+    ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=17, seg_base=3)
+    for b in range(2):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=17, seg=3 + b, rs_type=rs_type)
+        assert np.array_equal(pop.download(b), ref.pop)
+        assert ll[b] == ref.ll
+    pf.close()
+
+
+def test_resampler_choice_through_the_closure(dp, orc, pooley):
+    f = dp.get_particle_filter_lpdf(dp.generate_model("SIS", [100, 1]), pooley, np=512, rs_type=2)
+    got = f([0.003, 0.1], seed=5)
+    assert got == orc.pf_loglik(f.filter.desc, 512, [0.003, 0.1], seed=5, rs_type=2).ll
+    with pytest.raises(dp.DpompError):
+        dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=7)
