@@ -10,6 +10,7 @@ from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, 
                     generate_weak_prior, get_observations, partial_gaussian_obs_model)
 from .smc2 import (ImportanceSample, compute_ess, compute_is_mu_covar, rs_systematic, run_ibis_analysis, run_pibis,
                    run_smc2_analysis)
+from .pmcmc import MCMCSample, RejectionSample, gelman_sre, handle_rej_samples, run_pmcmc, run_pmcmc_analysis
 from . import parallel  # noqa: F401
 from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population,
                               get_particle_filter_lpdf)
