@@ -11,6 +11,7 @@ from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, 
 from .smc2 import (ImportanceSample, compute_ess, compute_is_mu_covar, rs_systematic, run_ibis_analysis, run_pibis,
                    run_smc2_analysis)
 from .pmcmc import MCMCSample, RejectionSample, gelman_sre, handle_rej_samples, run_pmcmc, run_pmcmc_analysis
+from .sim import Event, Particle, SimResults, generate_observations, gillespie_sim, save_to_file
 from . import parallel  # noqa: F401
 from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population,
                               get_particle_filter_lpdf)

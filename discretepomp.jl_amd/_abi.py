@@ -92,6 +92,9 @@ _PROTOTYPES = {
     "dpomp_pop_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dpomp_simulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
                                  C.c_int64, C.POINTER(C.c_int64)]),
+    "dpomp_simulate_events": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_uint64, C.c_int64, C.c_int64,
+                                        C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int64)]),
     "dpomp_debug_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "dpomp_selftest_numerics": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

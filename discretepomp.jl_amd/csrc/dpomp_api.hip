@@ -33,12 +33,14 @@ constexpr int kGatherLdsMaxTiles = 8192;  // k_gather: tile boundaries (4 B each
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
 // particles per lane (chosen by how many particles the launch has, see pick_prop).
+typedef void (*SimFn)(SimArgs);
 struct PropSet {
     PropFn fn1, q2, q4, c16, c32;
+    SimFn sim;
 };
 #define DPOMP_PROPSET(...)                                                                     \
     {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>, \
-     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>}
+     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>, k_simulate_rec<__VA_ARGS__>}
 
 struct PropEntry {
     int builtin, S, E;
@@ -72,7 +74,7 @@ PropSet generic_set(int S, int E) {
     DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
     DPOMP_G(8, 4) DPOMP_G(8, 8)
 #undef DPOMP_G
-    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr};
+    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 struct KernelStat {
@@ -96,7 +98,7 @@ struct dpomp_handle {
     std::vector<double> obs_time;
     std::vector<int64_t> obs_id;
     std::vector<long long> ysum;
-    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr};
+    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
     int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
                         // many particles per lane; 16, 32 = compaction every that many events
@@ -694,6 +696,61 @@ int dpomp_simulate(dpomp_handle* h, const double* theta, int64_t B, int64_t P, u
     }
     (void)hipFree(rec);
     pop_release(p);
+    return rc;
+}
+
+int dpomp_simulate_events(dpomp_handle* h, const double* theta, int64_t P, uint64_t seed, int64_t seg, int64_t max_events,
+                          int64_t* out_counts, double* out_times, int32_t* out_types, int64_t* out_states) {
+    if (!h) return DPOMP_EINVAL;
+    if (!theta || !out_counts || !out_times || !out_types || !out_states) return fail(h, DPOMP_EINVAL, "NULL argument");
+    if (P < 1 || max_events < 1 || P * max_events > ((int64_t)1 << 31)) return fail(h, DPOMP_EINVAL, "P * max_events out of range (1 .. 2^31)");
+    if (seg < 0 || seg > 0xFFFFFFFFll) return fail(h, DPOMP_EINVAL, "seg out of range");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int S = h->dm.S, T = h->T, K = h->dm.K;
+    SimArgs a;
+    a.m = h->dm;
+    double *d_theta = nullptr, *d_obs = nullptr, *d_time = nullptr;
+    long long *d_counts = nullptr, *d_states = nullptr;
+    int32_t* d_type = nullptr;
+    const size_t nev = (size_t)P * max_events;
+    hipError_t e = hipMalloc((void**)&d_theta, (size_t)K * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_obs, (size_t)T * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_counts, (size_t)P * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_states, (size_t)T * S * P * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_time, nev * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_type, nev * 4);
+    int rc = DPOMP_OK;
+    if (e != hipSuccess) {
+        rc = fail(h, DPOMP_ENOMEM, "hipMalloc for the event record: %s", hipGetErrorString(e));
+    } else {
+        (void)hipMemcpyAsync(d_theta, theta, (size_t)K * 8, hipMemcpyHostToDevice, h->stream);
+        (void)hipMemcpyAsync(d_obs, h->obs_time.data(), (size_t)T * 8, hipMemcpyHostToDevice, h->stream);
+        a.theta = d_theta;
+        a.obs_time = d_obs;
+        a.counts = d_counts;
+        a.ev_time = d_time;
+        a.ev_type = d_type;
+        a.states = d_states;
+        a.max_events = max_events;
+        a.P = (int32_t)P;
+        a.T = T;
+        a.seg = (uint32_t)seg;
+        a.seed = seed;
+        hipLaunchKernelGGL(h->prop.sim, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, a);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_states, d_states, (size_t)T * S * P * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_times, d_time, nev * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(out_types, d_type, nev * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, DPOMP_EDEVICE, "simulate_events: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_theta);
+    (void)hipFree(d_obs);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_states);
+    (void)hipFree(d_time);
+    (void)hipFree(d_type);
     return rc;
 }
 

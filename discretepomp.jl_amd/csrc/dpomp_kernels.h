@@ -646,6 +646,79 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     }
 }
 
+// ---- k_simulate_rec: forward simulation with event recording -------------------------------------------
+// gillespie_sim (hmm_sim.jl:86-102): one trajectory per lane through all T observation intervals in one
+// launch (no resampling between them), every executed event appended as (time, 1-based type) to the
+// lane's column of event-major buffers (coalesced across lanes), state recorded at each observation time.
+struct SimArgs {
+    DevModel m;
+    const double* theta;     // [K]
+    const double* obs_time;  // [T]
+    long long* counts;       // [P] events recorded, -1 = max_events exceeded (truncated)
+    double* ev_time;         // [max_events][P]
+    int32_t* ev_type;        // [max_events][P]
+    long long* states;       // [T][S][P]
+    int64_t max_events;
+    int32_t P, T;
+    uint32_t seg;
+    uint64_t seed;
+};
+
+template <class R>
+__global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
+    constexpr int S = R::S, E = R::E;
+    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= a.P) return;
+    const int s_real = R::kGeneric ? a.m.S : S;
+    const int e_real = R::kGeneric ? a.m.E : E;
+    int x[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = (s < s_real) ? a.m.x0[s] : 0;
+    double time = a.m.t0_index > 0 ? a.theta[a.m.t0_index - 1] : 0.0;
+    long long n = 0;
+    bool overflow = false;
+    for (int k = 0; k < a.T; ++k) {
+        Stream rng = stream_init(a.seed, a.seg, (uint32_t)p, (uint32_t)k, DOMAIN_SIMULATE);
+        const double tmax = a.obs_time[k];
+        while (!overflow) {
+            double cum[E];
+            R::rates(a.m, a.theta, x, cum);
+#pragma unroll
+            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+            const double tot = cum[E - 1];
+            if (tot == 0.0) break;
+            time = time - dlog(u01(stream_next(rng))) / tot;
+            if (time > tmax) break;
+            const double etc = u01(stream_next(rng)) * tot;
+            TW tw = (TW)a.m.trans_packed[e_real - 1];
+            int ev = e_real - 1;
+#pragma unroll
+            for (int i = E - 2; i >= 0; --i) {
+                const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                if (in_range && cum[i] > etc) {
+                    tw = (TW)a.m.trans_packed[i];
+                    ev = i;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+            if (n >= a.max_events) {
+                overflow = true;
+                break;
+            }
+            a.ev_time[n * a.P + p] = time;
+            a.ev_type[n * a.P + p] = ev + 1;
+            ++n;
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (s < s_real) a.states[((int64_t)k * s_real + s) * a.P + p] = x[s];
+        time = tmax;
+    }
+    a.counts[p] = overflow ? -1 : n;
+}
+
 // ---- weights -----------------------------------------------------------------------------------
 struct WeightArgs {
     const double* logw;                 // [B][Pp]

@@ -183,6 +183,24 @@ class ParticleFilter:
                                              out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 
+    def simulate_events(self, theta, n_sims: int = 1, seed: int = 1, seg: int = 0, max_events: int = 196000):
+        """Forward simulations with their event histories.  Returns (counts[n], times[n][..], types[n][..],
+        states[T, S, n]); ``counts[i] == -1`` marks a trajectory truncated at ``max_events`` (MAX_TRAJ)."""
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        if th.shape != (self.n_params,):
+            raise ValueError(f"theta must have length {self.n_params}")
+        n = int(n_sims)
+        counts = np.empty(n, dtype=np.int64)
+        times = np.empty((max_events, n), dtype=np.float64)
+        types = np.empty((max_events, n), dtype=np.int32)
+        states = np.empty((self.n_obs, self.n_states, n), dtype=np.int64)
+        self._check(self._lib.dpomp_simulate_events(self._h, _dptr(th), n, int(seed) & (2**64 - 1), int(seg), int(max_events),
+                                                    counts.ctypes.data_as(C.POINTER(C.c_int64)), _dptr(times),
+                                                    types.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    states.ctypes.data_as(C.POINTER(C.c_int64))))
+        m = np.where(counts < 0, max_events, counts)
+        return counts, [times[: m[i], i].copy() for i in range(n)], [types[: m[i], i].copy() for i in range(n)], states
+
     # -- inspection ---------------------------------------------------------------------
     def last_event_count(self) -> int:
         ev = C.c_uint64()

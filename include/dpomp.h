@@ -22,6 +22,7 @@
  *   dpomp_pop_upload     <- writing it before the call
  *   dpomp_simulate       <- gillespie_sim (final states at each observation time only)
  *                           src/hmm_sim.jl:86-102, iterate_particle! :55-70
+ *   dpomp_simulate_events<- gillespie_sim with the Event history (`p.trajectory`)
  *
  * Conventions
  *   - every function returns 0 (DPOMP_OK) or a negative DPOMP_E* code; the text of
@@ -190,6 +191,15 @@ int dpomp_pop_upload(dpomp_handle* h, dpomp_pop* pop, int64_t b, const int64_t* 
  * recording the state at each observation time: out[((b*T + t)*S + s)*P + p]. */
 int dpomp_simulate(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
                    int64_t seg_base, int64_t* out);
+
+/* gillespie_sim with its event history (hmm_sim.jl:86-102, `push!(p.trajectory, Event(time, et))` :65):
+ * P independent trajectories of parameter vector theta[K].  Buffers are EVENT-major:
+ * out_times[n*P + p], out_types[n*P + p] (1-based event type) for n < out_counts[p];
+ * out_counts[p] = -1 when more than max_events occurred (record truncated, cf. MAX_TRAJ hmm_sim.jl:17-20).
+ * out_states[(t*S + s)*P + p] = state at observation time t. */
+int dpomp_simulate_events(dpomp_handle* h, const double* theta, int64_t P, uint64_t seed, int64_t seg,
+                          int64_t max_events, int64_t* out_counts, double* out_times, int32_t* out_types,
+                          int64_t* out_states);
 
 /* ---- inspection (parity tests, bench) ----------------------------------------- */
 #define DPOMP_DBG_LOGW 1          /* double[P]  log-weights of the last weighted observation */

@@ -534,6 +534,42 @@ int orc_simulate(const dpomp_model_desc* d, int64_t P, const double* theta, uint
     return DPOMP_OK;
 }
 
+/* One forward simulation with its event history: gillespie_sim (hmm_sim.jl:86-102) with
+ * iterate_particle! (:55-70) -- `push!(p.trajectory, Event(time, et))` :65 for every executed event.
+ * Event types are reported 1-based as in the reference.  Returns the number of events, or -1 when
+ * `max_events` would be exceeded (the trajectory is then truncated). */
+int64_t orc_simulate_events(const dpomp_model_desc* d, const double* theta, uint64_t seed, uint32_t seg,
+                            uint32_t p, int64_t max_events, double* out_times, int32_t* out_types,
+                            int64_t* out_states /* [T][S] */) {
+    const int S = d->n_states, T = d->n_obs, E = d->n_events;
+    int64_t x[DPOMP_MAX_STATES];
+    for (int i = 0; i < S; ++i) x[i] = d->initial_condition[i];
+    double time = d->t0_index == 0 ? 0.0 : theta[d->t0_index - 1];
+    int64_t n = 0;
+    int overflow = 0;
+    for (int k = 0; k < T; ++k) {
+        uint64_t s[2];
+        orc_stream_init(seed, seg, p, (uint32_t)k, ORC_DOMAIN_SIMULATE, s);
+        double cum[DPOMP_MAX_EVENTS];
+        while (!overflow) {
+            orc_rates(d, theta, x, cum);
+            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+            if (cum[E - 1] == 0.0) break;
+            time -= orc_dlog(orc_u01(orc_stream_next(s))) / cum[E - 1];
+            if (time > d->obs_time[k]) break;
+            int ev = orc_choose_event(cum, E, orc_u01(orc_stream_next(s)));
+            for (int i = 0; i < S; ++i) x[i] += d->transition[ev][i];
+            if (n >= max_events) { overflow = 1; break; }
+            out_times[n] = time;
+            out_types[n] = ev + 1;
+            ++n;
+        }
+        for (int i = 0; i < S; ++i) out_states[(int64_t)k * S + i] = x[i];
+        time = d->obs_time[k]; /* t = y[i].time  hmm_sim.jl:98 */
+    }
+    return overflow ? -1 : n;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

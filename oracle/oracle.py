@@ -62,6 +62,9 @@ def lib():
                                      C.POINTER(C.c_uint64), C.POINTER(Trace)]
         L.orc_pf_loglik.argtypes = [C.c_void_p, C.c_int64, dp, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, dp,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(Trace)]
+        L.orc_simulate_events.restype = C.c_int64
+        L.orc_simulate_events.argtypes = [C.c_void_p, dp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, dp,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         L.orc_simulate.argtypes = [C.c_void_p, C.c_int64, dp, C.c_uint64, C.c_uint32, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -164,6 +167,17 @@ def simulate(desc, P, theta, seed=1, seg=0):
     th = np.ascontiguousarray(theta, dtype=np.float64)
     lib().orc_simulate(C.addressof(desc.c), P, _dp(th), seed, seg, _ip(out))
     return out
+
+
+def simulate_events(desc, theta, seed=1, seg=0, p=0, max_events=196000):
+    th = np.ascontiguousarray(theta, dtype=np.float64)
+    times = np.empty(max_events)
+    types = np.empty(max_events, dtype=np.int32)
+    states = np.empty((desc.n_obs, desc.n_states), dtype=np.int64)
+    n = lib().orc_simulate_events(C.addressof(desc.c), _dp(th), seed, seg, p, max_events, _dp(times),
+                                  types.ctypes.data_as(C.POINTER(C.c_int32)), _ip(states))
+    m = max_events if n < 0 else n
+    return n, times[:m].copy(), types[:m].copy(), states
 
 
 def max_threads():
