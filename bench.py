@@ -31,10 +31,24 @@ def algorithmic_bytes(P, S):
     return {
         "k_propagate": (2 * S + 1) * 8 * P,   # read state, write state, write log-weight
         "k_wsum": 8 * P,                      # normalise: read weight
-        "k_scan_blocks": 0,
+        "k_scan_blocks": 0,                   # tile sums only (final observation; fused into k_offsets otherwise)
         "k_offsets": 16 * P,                  # scan: read 8 + write 8
         "k_gather": (2 * S + 1) * 8 * P,      # resample: read cum. weight + gather state + write state
     }
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md: FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no profile is present."""
+    best = None
+    root = os.path.join(ROOT, "profiles")
+    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        f = os.path.join(root, d, "pmc_hbm_traffic.json")
+        if os.path.exists(f):
+            for name, v in json.load(open(f)).items():
+                if name.split("::")[-1].split("<")[0] == kernel:
+                    best = (v.get("hbm_bytes_per_launch_corrected"), d)
+    return best
 
 
 def cpu_baseline(dp, P_serial, P_parallel):
@@ -52,6 +66,8 @@ def cpu_baseline(dp, P_serial, P_parallel):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
+    # one GPU's share of the host (an 8-GPU MI355X node has 128 cores / 256 threads): 16 threads by default
+    cores = max(1, min(cores, int(os.environ.get("DPOMP_CPU_THREADS", "16"))))
     orc.pf_loglik(desc, 4096, THETA, seed=2, nthreads=cores)  # spin the thread pool up
     t0 = time.perf_counter()
     rp = orc.pf_loglik(desc, P_parallel, THETA, seed=1, nthreads=cores)
@@ -168,7 +184,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(g.get("achieved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
-            "traffic": None,
+            "traffic": (pmc_traffic("k_gather") or (None, None))[0],
+            "traffic_source": (pmc_traffic("k_gather") or (None, "none"))[1],
             "note": "memory-bound stage (normalise+scan+resample); k_propagate, which holds >95% of the "
                     "time, is FP64-VALU/divergence bound (SURVEY.md 8d) and is reported under 'propagate'",
         }
