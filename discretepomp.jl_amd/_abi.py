@@ -88,6 +88,7 @@ _PROTOTYPES = {
                                    C.c_uint64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "dpomp_pop_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "dpomp_pop_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    "dpomp_pop_device_state": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "dpomp_pop_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dpomp_pop_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "dpomp_simulate": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
@@ -112,11 +113,34 @@ class DpompLibraryMissing(RuntimeError):
     pass
 
 
+def _bind_to_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (same soname as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the device ("No HIP GPUs are available" for the second), so
+    when torch is installed this library binds to torch's copy, whichever of the two is loaded first.
+    Without torch (e.g. from Julia) the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # already in the process; the soname lookup below resolves to it
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load_library() -> C.CDLL:
     """Load libdpomp_hip.so (built by ``__graft_entry__.build()`` / ``build.py``)."""
     global _lib
     if _lib is not None:
         return _lib
+    _bind_to_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise DpompLibraryMissing(
             f"{LIB_PATH} not found: build the HIP extension first "

@@ -641,6 +641,15 @@ int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const 
     return DPOMP_OK;
 }
 
+int dpomp_pop_device_state(dpomp_handle* h, dpomp_pop* p, int for_write, void** device_ptr, int64_t* stride) {
+    if (!h) return DPOMP_EINVAL;
+    if (!p || !device_ptr || !stride) return fail(h, DPOMP_EINVAL, "NULL argument");
+    *device_ptr = p->state[p->cur];
+    *stride = p->Pp;
+    if (for_write) p->initialised = true;
+    return DPOMP_OK;
+}
+
 int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* p, int64_t b, int64_t* out) {
     if (!h) return DPOMP_EINVAL;
     if (!p || !out || b < 0 || b >= p->B) return fail(h, DPOMP_EINVAL, "bad pop/out/b");

@@ -75,3 +75,85 @@ def sharded_loglik(evaluate: Callable[[np.ndarray, int], np.ndarray], theta: np.
     if local.shape != (hi - lo,):
         raise ValueError("evaluate must return one value per segment of its block")
     return all_gather_segments(local, B, group)
+
+
+class LocalBank:
+    """The bank interface of the SMC^2 driver on one process: all N theta-particles on this GPU."""
+
+    def __init__(self, bank, N: int, npf: int):
+        self.bank, self.N = bank, N
+        self.pop = bank.alloc_population(N, npf)
+        self.pop_f = bank.alloc_population(N, npf)
+
+    def increment(self, theta, ymin, ymax, seed):
+        return self.bank.partial_log_likelihood(self.pop, theta, ymin, ymax, seed=seed)
+
+    def resample(self, nidx):
+        self.pop.gather(nidx)
+
+    def propose(self, theta_f, ymin, ymax, seed):
+        return self.bank.partial_log_likelihood(self.pop_f, theta_f, ymin, ymax, seed=seed)
+
+    def accept(self, mask):
+        self.pop.take(self.pop_f, np.where(mask, np.arange(self.N), -1))
+
+    def close(self):
+        for p in (self.pop, self.pop_f):
+            c = getattr(p, "close", None)
+            if c:
+                c()
+
+
+class ShardedBank(LocalBank):
+    """The same interface with the N theta-particles sharded over the process group: rank r owns the block
+    ``shard_bounds(N, world, r)`` and its device-resident populations.  Filters run locally with the GLOBAL
+    segment index in the RNG key; only log-likelihood vectors are all-gathered (8 B per theta-particle), except at
+    theta-level resampling (src/hmm_ibis.jl:70-75), where ancestors may live on another GPU: every rank
+    all-gathers the populations (int32 state, directly from device memory over RCCL) and keeps the rows of its
+    new block.  Results are bit-identical to :class:`LocalBank`."""
+
+    def __init__(self, bank, N: int, npf: int, group=None):
+        import torch.distributed as dist
+        self.bank, self.N, self.group = bank, N, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.lo, self.hi = shard_bounds(N, self.world, self.rank)
+        self.width = -(-N // self.world)
+        nb = max(self.hi - self.lo, 1)
+        self.empty = self.hi == self.lo
+        self.pop = bank.alloc_population(nb, npf)
+        self.pop_f = bank.alloc_population(nb, npf)
+
+    def _local(self, pop, theta, ymin, ymax, seed):
+        if self.empty:
+            return np.empty(0)
+        return self.bank.partial_log_likelihood(pop, np.ascontiguousarray(theta[:, self.lo:self.hi]), ymin, ymax,
+                                                seed=seed, seg_base=self.lo)
+
+    def increment(self, theta, ymin, ymax, seed):
+        return all_gather_segments(self._local(self.pop, theta, ymin, ymax, seed), self.N, self.group)
+
+    def propose(self, theta_f, ymin, ymax, seed):
+        return all_gather_segments(self._local(self.pop_f, theta_f, ymin, ymax, seed), self.N, self.group)
+
+    def resample(self, nidx):
+        import torch
+        import torch.distributed as dist
+        mine = self.pop.export_state()
+        pad = torch.zeros((self.width,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        if not self.empty:
+            pad[: self.hi - self.lo] = mine
+        everything = torch.empty((self.world * self.width,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(everything, pad, group=self.group)
+        if self.empty:
+            return
+        rows = []
+        for g in np.asarray(nidx[self.lo:self.hi]):
+            r = shard_of(int(g), self.N, self.world)
+            rows.append(r * self.width + int(g) - shard_bounds(self.N, self.world, r)[0])
+        self.pop.import_state(everything[torch.as_tensor(rows, device=mine.device)])
+
+    def accept(self, mask):
+        if self.empty:
+            return
+        m = np.asarray(mask[self.lo:self.hi])
+        self.pop.take(self.pop_f, np.where(m, np.arange(self.hi - self.lo), -1))

@@ -77,6 +77,28 @@ class Population:
             raise ValueError("one ancestor per segment")
         self._pf._check(self._pf._lib.dpomp_pop_gather(self._pf._h, self._ptr, a.ctypes.data_as(C.POINTER(C.c_int64))))
 
+    def state_tensor(self, for_write: bool = False):
+        """Zero-copy ``torch`` view of the device-resident populations, int32 ``[B, S, stride]`` (lanes
+        >= P of the last axis are padding).  Valid until the next resampling / gather on this population."""
+        import torch
+        ptr, stride = C.c_void_p(), C.c_int64()
+        self._pf._check(self._pf._lib.dpomp_pop_device_state(self._pf._h, self._ptr, 1 if for_write else 0,
+                                                            C.byref(ptr), C.byref(stride)))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (self.B, self._pf.n_states, int(stride.value)), "typestr": "<i4",
+                                        "data": (int(ptr.value), False), "version": 2, "strides": None}
+        return torch.as_tensor(_View(), device=torch.device("cuda", self._pf.device))
+
+    def export_state(self):
+        """Populations as a tensor for migration between ranks (a view, no copy)."""
+        return self.state_tensor(False)
+
+    def import_state(self, t):
+        self.state_tensor(True).copy_(t)
+        import torch
+        torch.cuda.current_stream(self._pf.device).synchronize()
+
     def take(self, other: "Population", take: Sequence[int]):
         """``self[b] <- other[take[b]]`` where ``take[b] >= 0`` (accepted PMMH proposals,
         src/hmm_ibis.jl:109)."""
@@ -98,6 +120,7 @@ class ParticleFilter:
                  essc: float = C_DF_ESS_CRIT, force_generic: bool = False):
         self._lib = _abi.load_library()
         self._h = C.c_void_p()
+        self.device = int(device)
         self.model = model
         self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic)
         self.n_states, self.n_params, self.n_obs = self.desc.n_states, self.desc.n_params, self.desc.n_obs

@@ -101,7 +101,7 @@ class _Proposal:
 
 def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool, alpha: float, npf: int,
               n_props: int = 1, seed: int = 1, rng: Optional[np.random.Generator] = None, verbose: bool = True,
-              proposal_correction: bool = False) -> ImportanceSample:
+              proposal_correction: bool = False, distributed: bool = False, group=None) -> ImportanceSample:
     """SMC^2 over the theta-particles ``theta`` (K x N).  ``bank`` is a :class:`ParticleFilter` (or any
     object with ``alloc_population``, ``partial_log_likelihood``, ``n_obs``, ``desc.obs_id``).
 
@@ -119,8 +119,8 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
 
     w = np.ones(N)
     aw = np.array([prior.logpdf(theta[:, i]) for i in range(N)])
-    pop = bank.alloc_population(N, npf)
-    pop_f = bank.alloc_population(N, npf)
+    from .parallel import LocalBank, ShardedBank
+    sb = ShardedBank(bank, N, npf, group) if distributed else LocalBank(bank, N, npf)
     mu, cv = np.zeros(K), np.zeros((K, K))
     k_log = [0, 0]
     bme = np.zeros(2)
@@ -137,7 +137,7 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
     for obs_i in range(1, T + 1):
         if obs_id[obs_i - 1] <= 0:
             continue
-        gx = bank.partial_log_likelihood(pop, theta, obs_min, obs_i, seed=next_seed())  # :53-56
+        gx = sb.increment(theta, obs_min, obs_i, next_seed())  # :53-56
         aw += gx
         gx = np.exp(gx)
         lml = math.log(np.sum(w * gx) / np.sum(w))  # :59
@@ -150,7 +150,7 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
             nidx = rs_systematic(w, rng)  # :70
             theta = np.ascontiguousarray(theta[:, nidx])
             aw = aw[nidx]
-            pop.gather(nidx)  # :74
+            sb.resample(nidx)  # :74
             mlr = float(np.mean(gx[nidx])) * math.exp(lml)
             k_log[0] += N
             mtd_gx = gx[nidx].copy()
@@ -163,11 +163,11 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
                     continue
                 th_run = np.where(ok[None, :], theta_f, theta)  # invalid proposals run a harmless theta, then are ignored
                 if obs_i == 1:  # :92-94
-                    gx_f = bank.partial_log_likelihood(pop_f, th_run, 1, 1, seed=next_seed())
+                    gx_f = sb.propose(th_run, 1, 1, next_seed())
                     aw_f = gx_f.copy()
                 else:  # :95-100
-                    aw_f = bank.partial_log_likelihood(pop_f, th_run, 1, obs_i - 1, seed=next_seed())
-                    gx_f = bank.partial_log_likelihood(pop_f, th_run, obs_i, obs_i, seed=next_seed())
+                    aw_f = sb.propose(th_run, 1, obs_i - 1, next_seed())
+                    gx_f = sb.propose(th_run, obs_i, obs_i, next_seed())
                     aw_f = aw_f + gx_f
                 aw_f = aw_f + prtf
                 log_ratio = aw_f - aw
@@ -181,7 +181,7 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
                     mtd_gx[accept] = np.exp(gx_f[accept])
                     theta[:, accept] = theta_f[:, accept]
                     aw[accept] = aw_f[accept]
-                    pop.take(pop_f, np.where(accept, np.arange(N), -1))  # pop[p] .= pop_f  :109
+                    sb.accept(accept)  # pop[p] .= pop_f  :109
                 n_acc = int(accept.sum())
                 k_log[1] += n_acc
                 tj *= alpha ** n_acc * 0.999 ** int(ok.sum() - n_acc)  # :111-113, applied per sweep
@@ -196,17 +196,14 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
     if verbose:
         ar = f"{100.0 * out.acceptance_rate:.3g}" if k_log[0] else "n/a"
         print(f"- finished in {out.run_time / 1e9:.1f} seconds (AR = {ar}%)")
-    for p_ in (pop, pop_f):
-        close = getattr(p_, "close", None)
-        if close:
-            close()
+    sb.close()
     return out
 
 
 def run_smc2_analysis(model: DPOMPModel, obs_data, np_: int = C_DF_SMC2_P, npf: int = C_DF_PF_P,
                       ess_rs_crit: float = C_DF_ESS_CRIT, ind_prop: bool = True, alpha: float = C_ACCEPTANCE_ALPHA,
-                      seed: int = 1, device: int = 0, verbose: bool = True, proposal_correction: bool = False
-                      ) -> ImportanceSample:
+                      seed: int = 1, device: int = 0, verbose: bool = True, proposal_correction: bool = False,
+                      distributed: bool = False) -> ImportanceSample:
     """``run_smc2_analysis(model, obs_data; np, npf, ess_rs_crit, ind_prop, alpha)`` (src/DiscretePOMP.jl:251-257).
     (``np_`` because ``np`` is numpy here.)"""
     rng = np.random.default_rng(seed)
@@ -216,7 +213,7 @@ def run_smc2_analysis(model: DPOMPModel, obs_data, np_: int = C_DF_SMC2_P, npf: 
         print(f"Running: {np_}-particle SMC^2 analysis (model: {model.model_name})")
     try:
         return run_pibis(bank, model.prior, theta_init, ess_rs_crit, ind_prop, alpha, npf, seed=seed, rng=rng,
-                         verbose=verbose, proposal_correction=proposal_correction)
+                         verbose=verbose, proposal_correction=proposal_correction, distributed=distributed)
     finally:
         bank.close()
 

@@ -183,6 +183,12 @@ int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* pop, const int64_t* ancestors);
  * population): installs the populations of accepted proposals, hmm_ibis.jl:109.  dst and src are
  * distinct handles of the same filter with equal P. */
 int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const int64_t* take);
+/* Zero-copy interop (RCCL / torch.distributed population migration): device pointer of the
+ * populations as int32 [B][S][stride] (stride = P rounded up to 1024; lanes >= P are padding).
+ * Valid until the next call on this population that resamples or gathers (those swap buffers).
+ * for_write != 0 also marks the population initialised (the caller is about to fill it). */
+int dpomp_pop_device_state(dpomp_handle* h, dpomp_pop* pop, int for_write, void** device_ptr,
+                           int64_t* stride);
 /* Segment b as a P x S column-major Int64 matrix. */
 int dpomp_pop_download(dpomp_handle* h, const dpomp_pop* pop, int64_t b, int64_t* out);
 int dpomp_pop_upload(dpomp_handle* h, dpomp_pop* pop, int64_t b, const int64_t* in);

@@ -75,3 +75,43 @@ def test_single_process_is_identity(dp):
     th = np.array([[0.003, 0.004], [0.1, 0.2]])
     out = parallel.sharded_loglik(lambda t, base: t[0] * 1000 + base, th)
     assert np.array_equal(out, [3.0 + 0, 4.0 + 0])
+
+
+def _smc2_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dpomp_amd as dp
+    from helpers import OracleBank
+    from oracle import oracle as orc
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    theta0 = prior.rand(np.random.default_rng(5), 51)  # odd count: blocks of 26 and 25
+    out = dp.run_pibis(OracleBank(dp, orc, model, y), prior, theta0, 0.3, True, 1.002, 64, seed=9,
+                       rng=np.random.default_rng(11), verbose=False, distributed=True)
+    np.savez(os.path.join(out_dir, f"smc2_rank{rank}.npz"), bme=out.bme, theta=out.theta, weight=out.weight, nres=out.n_resample)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_smc2_equals_single_process(tmp_path, dp, orc):
+    """SMC^2 with the theta-particles sharded over 2 ranks (populations migrate at theta-level resampling)
+    walks exactly the path of the single-process run."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import OracleBank
+    mp.spawn(_smc2_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    theta0 = prior.rand(np.random.default_rng(5), 51)
+    ref = dp.run_pibis(OracleBank(dp, orc, model, y), prior, theta0, 0.3, True, 1.002, 64, seed=9,
+                       rng=np.random.default_rng(11), verbose=False)
+    assert ref.n_resample >= 1
+    for r in range(2):
+        got = np.load(tmp_path / f"smc2_rank{r}.npz")
+        assert np.array_equal(got["bme"], ref.bme) and np.array_equal(got["theta"], ref.theta) and np.array_equal(got["weight"], ref.weight)

@@ -3,44 +3,18 @@ value of -ln evidence (19.98, test/runtests.jl:48-52); the exact value under tha
 import json
 import os
 
+import sys
+
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EXACT = json.load(open(os.path.join(GOLDEN, "pf_golden.json")))["exact_pooley_sis_evidence_u001_u05"]
 
 
-class OraclePop:
-    def __init__(self, B, P, S):
-        self.B, self.P = B, P
-        self.pops = [np.zeros((P, S), dtype=np.int64) for _ in range(B)]
-
-    def gather(self, anc):
-        self.pops = [self.pops[a].copy() for a in anc]
-
-    def take(self, other, take):
-        for b, t in enumerate(take):
-            if t >= 0:
-                self.pops[b] = other.pops[t].copy()
-
-    def close(self):
-        pass
-
-
-class OracleBank:
-    """Same surface as ParticleFilter, computed by the CPU oracle (tests only)."""
-
-    def __init__(self, dp, orc, model, obs):
-        self.orc, self.desc = orc, dp.ModelDescriptor(model, obs)
-        self.n_obs, self.n_states = self.desc.n_obs, self.desc.n_states
-
-    def alloc_population(self, B, P):
-        return OraclePop(B, P, self.n_states)
-
-    def partial_log_likelihood(self, pop, theta, ymin, ymax, seed=1, seg_base=0):
-        theta = np.asarray(theta)
-        return np.array([self.orc.pf_partial(self.desc, pop.pops[b], theta[:, b], ymin, ymax, seed=seed, seg=seg_base + b).ll
-                         for b in range(pop.B)])
+from helpers import OracleBank, OraclePop  # noqa: E402,F401
 
 
 def test_theta_level_helpers(dp):
@@ -131,3 +105,34 @@ def test_smc2_gpu_equals_oracle_bank_at_same_seeds(dp, orc, pooley):
     b = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 128, seed=9, rng=np.random.default_rng(11), verbose=False)
     assert np.array_equal(a.bme, b.bme) and np.array_equal(a.theta, b.theta) and np.array_equal(a.weight, b.weight)
     pf.close()
+
+
+@pytest.mark.gpu
+def test_sharded_bank_on_gpu_matches_local_bank(dp, pooley):
+    """world_size-1 nccl group on the one GPU of the box: exercises the zero-copy torch view of the
+    device-resident populations and the RCCL all-gather of states used for theta-level migration."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        model = dp.generate_model("SIS", [100, 1])
+        prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+        theta0 = prior.rand(np.random.default_rng(5), 96)
+        pf = dp.ParticleFilter(model, pooley)
+        a = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 256, seed=9, rng=np.random.default_rng(11), verbose=False)
+        b = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 256, seed=9, rng=np.random.default_rng(11), verbose=False,
+                         distributed=True)
+        assert a.n_resample >= 1
+        assert np.array_equal(a.bme, b.bme) and np.array_equal(a.theta, b.theta) and np.array_equal(a.weight, b.weight)
+        # the view really aliases library memory
+        pop = pf.alloc_population(2, 300)
+        pf.partial_log_likelihood(pop, theta0[:, :2], 1, 2, seed=3)
+        view = pop.state_tensor()
+        assert tuple(view.shape) == (2, 2, 1024) and view.dtype == torch.int32
+        assert np.array_equal(view[1, :, :300].cpu().numpy().T, pop.download(1))
+        pf.close()
+    finally:
+        dist.destroy_process_group()
