@@ -126,12 +126,14 @@ struct dpomp_pop {
     int32_t* tile_end = nullptr;           // [B][nblk]
     double* posw = nullptr;                // [B][Pp]   (allocated on first use of resampler 2 / 3)
     double* tile_end_pos = nullptr;        // [B][nblk]
-    unsigned long long* segmax = nullptr;  // [T][B]
+    char* ctl = nullptr;                   // control block, see pop_alloc_impl
+    size_t ctl_bytes = 0, ctl_result_bytes = 0;
+    unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
     unsigned long long* wtot = nullptr;    // [B]
-    double* ll = nullptr;                  // [B]
-    uint32_t* status = nullptr;            // [B]
+    double* ll = nullptr;                  // [B]      (inside ctl)
+    uint32_t* status = nullptr;            // [B]      (inside ctl)
     double* theta = nullptr;               // [B][K]
-    unsigned long long* events = nullptr;  // [1]
+    unsigned long long* events = nullptr;  // [1]      (inside ctl)
     int64_t* ancestors = nullptr;          // [B]
     bool initialised = false;
     int last_weighted_obs = -1;
@@ -243,12 +245,9 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->tile_end);
     (void)hipFree(p->posw);
     (void)hipFree(p->tile_end_pos);
-    (void)hipFree(p->segmax);
+    (void)hipFree(p->ctl);
     (void)hipFree(p->wtot);
-    (void)hipFree(p->ll);
-    (void)hipFree(p->status);
     (void)hipFree(p->theta);
-    (void)hipFree(p->events);
     (void)hipFree(p->ancestors);
     delete p;
 }
@@ -281,12 +280,20 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->tile_end, (size_t)B * p->nblk * 4);
-    DPOMP_ALLOC(p->segmax, (size_t)p->T * B * 8);
+    // one control block: [ll B f64][events u64][status B u32, padded to 8 B][segmax T*B u64] -> one memset and one
+    // result download per call
+    {
+        const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
+        p->ctl_result_bytes = n_ll + n_ev + n_st;
+        p->ctl_bytes = p->ctl_result_bytes + n_sm;
+        DPOMP_ALLOC(p->ctl, p->ctl_bytes);
+        p->ll = reinterpret_cast<double*>(p->ctl);
+        p->events = reinterpret_cast<unsigned long long*>(p->ctl + n_ll);
+        p->status = reinterpret_cast<uint32_t*>(p->ctl + n_ll + n_ev);
+        p->segmax = reinterpret_cast<unsigned long long*>(p->ctl + p->ctl_result_bytes);
+    }
     DPOMP_ALLOC(p->wtot, (size_t)B * 8);
-    DPOMP_ALLOC(p->ll, (size_t)B * 8);
-    DPOMP_ALLOC(p->status, (size_t)B * 4);
     DPOMP_ALLOC(p->theta, (size_t)B * p->K * 8);
-    DPOMP_ALLOC(p->events, 8);
     DPOMP_ALLOC(p->ancestors, (size_t)B * 8);
 #undef DPOMP_ALLOC
     *out = p;
@@ -316,10 +323,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     const dim3 grid_tiles((unsigned)p->nblk, (unsigned)B);
 
     HIPCHK(h, hipMemcpyAsync(p->theta, theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemsetAsync(p->segmax, 0, (size_t)p->T * B * 8, st));
-    HIPCHK(h, hipMemsetAsync(p->ll, 0, (size_t)B * 8, st));
-    HIPCHK(h, hipMemsetAsync(p->status, 0, (size_t)B * 4, st));
-    HIPCHK(h, hipMemsetAsync(p->events, 0, 8, st));
+    HIPCHK(h, hipMemsetAsync(p->ctl, 0, p->ctl_bytes, st));
 
     if (ymin == 1) {  // pop[i,:] .= initial_condition  (:41-45)
         ScopedTiming tm(h, KID_INIT);
@@ -444,15 +448,13 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         t_prev = h->obs_time[k];  // :72
     }
     HIPCHK(h, hipGetLastError());
-    std::vector<uint32_t> status_host((size_t)B);
-    unsigned long long events = 0;
-    if (out_ll) HIPCHK(h, hipMemcpyAsync(out_ll, p->ll, (size_t)B * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(status_host.data(), p->status, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(&events, p->events, 8, hipMemcpyDeviceToHost, st));
+    std::vector<char> result(p->ctl_result_bytes);
+    HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     collect_timings(h);
-    h->last_events = events;
-    if (out_status) memcpy(out_status, status_host.data(), (size_t)B * 4);
+    if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
+    memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
+    if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
     return DPOMP_OK;
 }
 

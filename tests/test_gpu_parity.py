@@ -318,3 +318,22 @@ def test_resampler_choice_through_the_closure(dp, orc, pooley):
     assert got == orc.pf_loglik(f.filter.desc, 512, [0.003, 0.1], seed=5, rs_type=2).ll
     with pytest.raises(dp.DpompError):
         dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=7)
+
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name,x0,theta,csv", [("SEIR", [100, 0, 1, 0], [0.005, 0.2, 0.1], "seir_synthetic.csv"),
+                                               ("LOTKA", [70, 70], [0.5, 0.0025, 0.3], "lotka_synthetic.csv")])
+def test_baseline_config_shapes_at_scale(dp, orc, name, x0, theta, csv):
+    """BASELINE configs 3-5 on their committed synthetic data: exact parity at P = 512, then a large batched run
+    (4 x 2^16) whose estimates must agree with each other within Monte-Carlo scatter and raise no status flag."""
+    y = dp.get_observations(os.path.join(GOLDEN_DIR, csv))
+    pf = dp.ParticleFilter(dp.generate_model(name, x0), y)
+    small = pf.loglik(theta, 512, seed=6)[0]
+    assert small == orc.pf_loglik(pf.desc, 512, theta, seed=6).ll
+    big = pf.loglik(np.tile(np.array(theta)[:, None], (1, 4)), 1 << 16, seed=7)
+    assert np.all(np.isfinite(big)) and np.all(pf.last_status == 0)
+    assert big.max() - big.min() < 0.25, big   # four independent 65536-particle estimates of the same quantity
+    assert abs(big.mean() - small) < 1.5        # and the 512-particle estimate is in the same place
+    pf.close()
