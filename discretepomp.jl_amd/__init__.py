@@ -12,6 +12,7 @@ from .smc2 import (ImportanceSample, compute_ess, compute_is_mu_covar, rs_system
                    run_smc2_analysis)
 from .pmcmc import MCMCSample, RejectionSample, gelman_sre, handle_rej_samples, run_pmcmc, run_pmcmc_analysis
 from .sim import Event, Particle, SimResults, generate_observations, gillespie_sim, save_to_file
+from .arq import ARQMCMCSample, ARQModel, GridPoint, run_arq_mcmc_analysis, run_inner_mcmc_analysis
 from . import parallel  # noqa: F401
 from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population,
                               get_particle_filter_lpdf)
