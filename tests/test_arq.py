@@ -57,6 +57,9 @@ def test_arq_reference_configuration_on_gpu(dp, pooley):
     model.prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
     out = dp.run_arq_mcmc_analysis(model, pooley, [0.0005, 0.02], seed=1, verbose=False)
     assert out.samples.theta.shape == (2, 50000, 5) and int(out.fx.sum()) == len(out.sample_cache)
-    assert abs(out.imp_sample.mu[0] - REFERENCE_SEED1_MU1) < 0.03 * REFERENCE_SEED1_MU1, out.imp_sample.mu
-    assert abs(out.imp_sample.mu[0] - EXACT["beta_mean"]) < 0.03 * EXACT["beta_mean"]
-    assert abs(out.imp_sample.mu[1] - EXACT["gamma_mean"]) < 0.05 * EXACT["gamma_mean"]
+    # measured over 10 seeds on MI355X (tools/arq_spread.py): mu[0] = 0.003204 +- 0.000074, mu[1] = 0.1064 +- 0.0026;
+    # the reference's seed-1 value 0.003217 sits at +0.2 sd.  3.5 sd bands:
+    assert abs(out.imp_sample.mu[0] - REFERENCE_SEED1_MU1) < 0.00026, out.imp_sample.mu
+    assert abs(out.imp_sample.mu[0] - EXACT["beta_mean"]) < 0.0003
+    assert abs(out.imp_sample.mu[1] - EXACT["gamma_mean"]) < 0.011
+    assert 200 < len(out.sample_cache) <= 500   # a few hundred filter evaluations in total
