@@ -221,11 +221,13 @@ def run_smc2_analysis(model: DPOMPModel, obs_data, np_: int = C_DF_SMC2_P, npf: 
 def run_ibis_analysis(model: DPOMPModel, obs_data, algorithm: str = C_ALG_NM_SMC2, np_: Optional[int] = None,
                       ind_prop: Optional[bool] = None, ess_rs_crit: Optional[float] = None,
                       alpha: float = C_ACCEPTANCE_ALPHA, npf: int = C_DF_PF_P, seed: int = 1, device: int = 0,
-                      verbose: bool = True, proposal_correction: bool = False) -> ImportanceSample:
+                      verbose: bool = True, proposal_correction: bool = False, distributed: bool = False
+                      ) -> ImportanceSample:
     """``run_ibis_analysis`` (src/DiscretePOMP.jl:289-302).  Only the default algorithm, SMC^2, sits on
     the particle-filter path; "MBPI" (model-based-proposal IBIS) does not use the filter and is out of scope."""
     if algorithm != C_ALG_NM_SMC2:
         raise NotImplementedError("only algorithm='SMC2' uses the particle filter; MBP-IBIS is outside this path")
     return run_smc2_analysis(model, obs_data, np_ if np_ is not None else C_DF_SMC2_P, npf,
                              ess_rs_crit if ess_rs_crit is not None else C_DF_ESS_CRIT,
-                             True if ind_prop is None else ind_prop, alpha, seed, device, verbose, proposal_correction)
+                             True if ind_prop is None else ind_prop, alpha, seed, device, verbose, proposal_correction,
+                             distributed)
