@@ -129,7 +129,9 @@ DPOMP_HD uint64_t stream_next(Stream& s) {
 // and k 2^-52 + 2^-53 is representable, so this equals (double)(2k+1) * 2^-53 bit for bit.
 DPOMP_HD double u01(uint64_t x) {
     const double d = bits_to_double(0x3FF0000000000000ull | (x >> 12));
-    return (d - 1.0) + 0x1p-53;
+    // (d - 1) + 2^-53 in ONE add: the constant -(1 - 2^-53) is a double and the exact sum (2k+1) 2^-53 is
+    // representable, so the correctly rounded add returns it exactly.
+    return d + (-0x1.fffffffffffffp-1);
 }
 
 // log(x), positive normal x, table-driven and division-free (the structure of glibc's log):

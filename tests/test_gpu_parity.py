@@ -337,3 +337,56 @@ def test_baseline_config_shapes_at_scale(dp, orc, name, x0, theta, csv):
     assert big.max() - big.min() < 0.25, big   # four independent 65536-particle estimates of the same quantity
     assert abs(big.mean() - small) < 1.5        # and the 512-particle estimate is in the same place
     pf.close()
+
+
+def test_single_observation_no_resampling(dp, orc, make_obs):
+    """T = 1: propagate, weight, log mean weight -- and never resample (obs_i < length(obs_data) is false)."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), make_obs([30.0], [[0, 40]]))
+    pop = pf.alloc_population(1, 1500)
+    ll = pf.partial_log_likelihood(pop, [0.003, 0.1], 1, 1, seed=2)
+    ref = orc.pf_loglik(pf.desc, 1500, [0.003, 0.1], seed=2)
+    assert ll[0] == ref.ll and np.array_equal(pop.download(0), ref.pop)
+    pf.close()
+
+
+def test_zero_length_interval_and_zero_rates(dp, orc, make_obs):
+    """Two observations at the same time (nothing can happen in between) and a parameter vector with all
+    rates zero (total rate 0: particles idle without drawing, hmm_particle_filter.jl:22)."""
+    y = make_obs([10.0, 10.0, 25.0], [[0, 3], [0, 4], [0, 9]])
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), y)
+    for theta in ([0.003, 0.1], [0.0, 0.0]):
+        pop = pf.alloc_population(1, 640)
+        ll = pf.partial_log_likelihood(pop, theta, 1, 3, seed=5)
+        ref = orc.pf_loglik(pf.desc, 640, theta, seed=5)
+        assert ll[0] == ref.ll and np.array_equal(pop.download(0), ref.pop)
+        assert pf.last_event_count() == ref.events
+    assert pf.last_event_count() == 0   # theta = 0: no events at all, every particle still at [100, 1]
+    assert np.all(pop.download(0) == [100, 1])
+    pf.close()
+
+
+def test_maximum_model_size_through_the_generic_evaluator(dp, orc, make_obs):
+    """S = 8 states, E = 8 events, K = 8 parameters (the ABI's limits): a ring of compartments with every rate
+    form the table offers (plain, product, frequency-dependent, ratio)."""
+    T = dp.RateTerm
+    terms = [T(1, ((1,), (2,))), T(2, ((2,),)), T(3, ((3,), (4,)), tuple(range(1, 9))), T(4, ((4,),)),
+             T(5, ((5,), (6,)), (5, 6), "ratio"), T(6, ((6, 7),)), T(7, ((7,),)), T(8, ((8,), (1,)), (1, 2, 3))]
+    trans = np.zeros((8, 8), dtype=int)
+    for e in range(8):
+        trans[e, e] = -1
+        trans[e, (e + 1) % 8] = 1
+    x0 = [40, 30, 20, 25, 35, 15, 10, 30]
+    model = dp.generate_custom_model("RING8", dp.RateFunction(terms), x0, trans,
+                                     obs_model=dp.partial_gaussian_obs_model(3.0, seq=(2, 5, 8), y_seq=(1, 3)))
+    y = make_obs([2.0, 4.0, 6.0], [[40, 0, 30], [45, 0, 28], [50, 0, 25]])
+    theta = [0.002, 0.1, 0.5, 0.15, 0.3, 0.05, 0.2, 0.004]
+    pf = dp.ParticleFilter(model, y)
+    pop = pf.alloc_population(2, 900)
+    th2 = np.stack([theta, [t * 1.1 for t in theta]], axis=1)
+    ll = pf.partial_log_likelihood(pop, th2, 1, 3, seed=21)
+    for b in range(2):
+        ref = orc.pf_loglik(pf.desc, 900, th2[:, b], seed=21, seg=b)
+        assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
+    # host evaluation of the same table agrees with the oracle's interpreter
+    assert np.array_equal(model.rate_function(np.zeros(8), theta, x0), orc.rates(pf.desc, theta, x0))
+    pf.close()
