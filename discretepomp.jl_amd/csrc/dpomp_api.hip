@@ -26,6 +26,7 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 
 typedef void (*PropFn)(PropArgs);
 
+constexpr int64_t kCompactionMinWaves = 8192;
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
 constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
@@ -356,8 +357,10 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.want_weight = weighted ? 1 : 0;
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
+            // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
+            // taken by other waves); below that the plain kernel wins by 10-15 % (tools/latency_probe.py).
             int rpl = h->force_rpl;
-            if (rpl == 0) rpl = kDefaultPropVariant;
+            if (rpl == 0) rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves) ? kDefaultPropVariant : 1;
             PropFn fn = rpl == 4 ? h->prop.q4 : rpl == 2 ? h->prop.q2 : rpl == 16 ? h->prop.c16 : rpl == 32 ? h->prop.c32 : h->prop.fn1;
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
