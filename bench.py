@@ -24,6 +24,11 @@ POOLEY = [(20.0, [0, 18]), (40.0, [0, 65]), (60.0, [0, 70]), (80.0, [0, 66]), (1
 THETA = [0.003, 0.1]
 EXACT_LL = -15.6873794556  # exact CTMC forward algorithm (oracle/exact_sis.py)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# VALU-issue ceiling of k_propagate: the SIS inner loop is 42 FP64 + 60 integer VALU instructions per
+# event; FP64 issues at 4 cycles per wave64 instruction (78.6 TFLOP/s FP64 vector peak), integer at 2, plus ~32 cycles
+# for the quarter-rate v_rcp_f64 / v_div_* ops: ~320 cycles per 64 events per SIMD, 1024 SIMDs at 2.4 GHz.
+VALU_CYCLES_PER_WAVE_EVENT = 42 * 4 + 60 * 2 + 32
+VALU_CEILING_EVENTS_PER_S = 1024 * 2.4e9 * 64 / VALU_CYCLES_PER_WAVE_EVENT
 
 
 def algorithmic_bytes(P, S):
@@ -199,7 +204,10 @@ def main():
             "events_per_particle_per_call": round(events / world / args.steps / P, 1),
             "hbm_achieved_GBs": prop.get("achieved_GBs"),
             "bound": "fp64-valu + wave divergence (not HBM, not MFMA)",
+            "valu_ceiling_events_per_s": round(VALU_CEILING_EVENTS_PER_S),
         }
+        if propagate.get("events_per_s"):
+            propagate["valu_frac"] = round(propagate["events_per_s"] / VALU_CEILING_EVENTS_PER_S, 3)
         mean_ll = float(np.mean(lls))
         result = {
             "metric": "particle-steps/sec",
