@@ -30,7 +30,6 @@ constexpr int64_t kCompactionMinWaves = 8192;
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
 constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
-constexpr int kGatherLdsMaxTiles = 8192;  // k_gather: tile boundaries (4 B each) + 16 KB window must fit LDS
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
 // particles per lane (chosen by how many particles the launch has, see pick_prop).
@@ -431,19 +430,14 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                 g.src = p->state[p->cur];
                 g.dst = p->state[p->cur ^ 1];
                 g.offs = p->offs;
-                g.tile_end = p->tile_end;
+                g.first_parent = p->tile_end;
                 g.Pp = p->Pp;
                 g.P = (int32_t)p->P;
                 g.S = p->S;
                 g.nblk = p->nblk;
                 {
                     ScopedTiming tm(h, KID_GATHER);  // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67
-                    if (p->nblk <= kGatherLdsMaxTiles) {
-                        const size_t lds = (size_t)(kStageTiles * kTile + p->nblk) * sizeof(int32_t);
-                        hipLaunchKernelGGL(k_gather, grid_tiles, block, lds, st, g);
-                    } else {
-                        hipLaunchKernelGGL(k_gather_global, grid_tiles, block, 0, st, g);
-                    }
+                    hipLaunchKernelGGL(k_gather, grid_tiles, block, 0, st, g);
                 }
                 p->cur ^= 1;
             }

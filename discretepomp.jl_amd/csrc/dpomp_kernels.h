@@ -729,7 +729,7 @@ struct WeightArgs {
     double* ll;                         // [B] running log-likelihood
     uint32_t* status;                   // [B]
     int32_t* offs;                      // [B][Pp]
-    int32_t* tile_end;                  // [B][nblk] N of the last particle of each 1024-tile
+    int32_t* tile_end;                  // [B][nblk] first_parent: parent tile of the first slot of each output tile
     double* posw;                       // [B][Pp]   pos_j = c_j / W * P (stratified / multinomial resamplers)
     double* tile_end_pos;               // [B][nblk] pos of the last particle of each tile
     int64_t Pp;
@@ -866,7 +866,18 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         for (int q = 0; q < kItems; ++q)
             n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
         *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
-        if (threadIdx.x == kBlock - 1) a.tile_end[(int64_t)b * a.nblk + blk] = n[kItems - 1];
+        // Inverse map for k_gather: every 1024-slot OUTPUT tile t learns which parent tile its first slot
+        // (t * 1024) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
+        // t * 1024 writes first_parent[t] = its tile; exactly one writer per output tile, no cross-workgroup
+        // dependency (N_{j-1} is recomputed from the exclusive cumulative weight).
+        int lo = (W == 0) ? ((i0 == 0) ? 0 : a.P) : (int)offspring_end(base + c[0] - w[0], W, a.P, r);
+        int32_t* fp = a.tile_end + (int64_t)b * a.nblk;
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) {
+            const int hi = n[q];
+            for (int t = (lo + kTile - 1) / kTile; t * kTile < hi; ++t) fp[t] = blk;
+            lo = hi;
+        }
     } else {
         // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
         // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
@@ -883,17 +894,16 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------
-// Ancestor of slot i = first j with N_j > i.  N is monotone, so the 1024 output slots of a
-// workgroup draw from a contiguous window of parents.  The workgroup stages (a) the per-tile
-// boundary array tile_end (4 B per 1024 particles) and (b) the window of N it needs (up to
-// kStageTiles tiles) in LDS and every lane searches there (12 LDS steps, 4 searches interleaved);
-// wider windows (very uneven weights) fall back to tile_end in LDS + a 10-step search in L2.
-// Writes are 16 B per lane per component, reads of the parents are monotone in i.
+// Ancestor of slot i = first j with N_j > i.  N is monotone, so the 1024 output slots of a workgroup draw from
+// a contiguous window of parent tiles [first_parent[t], first_parent[t+1]] (written by k_offsets).  The
+// workgroup stages that window of N in LDS (up to kStageTiles tiles, coalesced 16-B loads) and every lane
+// searches there (12 LDS steps, its 4 searches interleaved); wider windows (very uneven weights) fall back to
+// a bounded binary search in L2.  Writes are 16 B per lane per component; parent reads are monotone in i.
 struct GatherArgs {
     const int32_t* src;  // [B][S][Pp]
     int32_t* dst;
-    const int32_t* offs;      // [B][Pp]
-    const int32_t* tile_end;  // [B][nblk]
+    const int32_t* offs;          // [B][Pp]  N_j
+    const int32_t* first_parent;  // [B][nblk]
     int64_t Pp;
     int32_t P, S, nblk;
 };
@@ -910,37 +920,14 @@ __device__ __forceinline__ int first_greater(Ptr N, int n, int i) {
     return lo;
 }
 
-// General form: global binary search per slot (any P; used when tile_end does not fit in LDS).
-__global__ __launch_bounds__(kBlock) void k_gather_global(GatherArgs a) {
-    const int b = blockIdx.y;
-    const int64_t i0 = (int64_t)blockIdx.x * kTile + threadIdx.x * kItems;
-    const int32_t* N = a.offs + (int64_t)b * a.Pp;
-    int j[kItems];
-#pragma unroll
-    for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? first_greater(N, a.P, (int)(i0 + q)) : 0;
-    for (int s = 0; s < a.S; ++s) {
-        const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
-        const int4 v = make_int4(src[j[0]], src[j[1]], src[j[2]], src[j[3]]);
-        *reinterpret_cast<int4*>(a.dst + ((int64_t)b * a.S + s) * a.Pp + i0) = v;
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
-    extern __shared__ __attribute__((aligned(16))) int32_t smem[];
-    int32_t* s_n = smem;                               // [kStageTiles * kTile] staged window of N
-    int32_t* s_te = smem + kStageTiles * kTile;        // [nblk] tile boundaries
-    __shared__ int s_tlo, s_thi;
-    const int b = blockIdx.y;
-    const int tile0 = blockIdx.x * kTile;
-    const int64_t i0 = (int64_t)tile0 + threadIdx.x * kItems;
+    __shared__ __attribute__((aligned(16))) int32_t s_n[kStageTiles * kTile];
+    const int b = blockIdx.y, t_out = blockIdx.x;
+    const int64_t i0 = (int64_t)t_out * kTile + threadIdx.x * kItems;
     const int32_t* N = a.offs + (int64_t)b * a.Pp;
-    const int32_t* TE = a.tile_end + (int64_t)b * a.nblk;
-    for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_te[t] = TE[t];
-    __syncthreads();
-    if (threadIdx.x == 0) s_tlo = first_greater(s_te, a.nblk, tile0);
-    if (threadIdx.x == 64) s_thi = first_greater(s_te, a.nblk, min(tile0 + kTile - 1, a.P - 1));
-    __syncthreads();
-    const int tlo = s_tlo, thi = s_thi;
+    const int32_t* fp = a.first_parent + (int64_t)b * a.nblk;
+    const int tlo = fp[t_out];
+    const int thi = (t_out + 1 < a.nblk) ? fp[t_out + 1] : a.nblk - 1;  // ancestors are monotone in the slot index
     const int ntiles = thi - tlo + 1;
     int j[kItems];
     if (ntiles <= kStageTiles) {
@@ -961,17 +948,11 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? tlo * kTile + lo[q] : 0;
+        for (int q = 0; q < kItems; ++q) j[q] = (i0 + q < a.P) ? min(tlo * kTile + lo[q], a.P - 1) : 0;
     } else {
 #pragma unroll
-        for (int q = 0; q < kItems; ++q) {
-            if (i0 + q < a.P) {
-                const int t = first_greater(s_te, a.nblk, (int)(i0 + q));
-                j[q] = t * kTile + first_greater(N + (int64_t)t * kTile, kTile, (int)(i0 + q));
-            } else {
-                j[q] = 0;
-            }
-        }
+        for (int q = 0; q < kItems; ++q)
+            j[q] = (i0 + q < a.P) ? tlo * kTile + first_greater(N + (int64_t)tlo * kTile, min(ntiles * kTile, a.P - tlo * kTile), (int)(i0 + q)) : 0;
     }
     for (int s = 0; s < a.S; ++s) {
         const int32_t* src = a.src + ((int64_t)b * a.S + s) * a.Pp;
