@@ -26,6 +26,7 @@ OBS_GAUSSIAN = 1
 RS_SYSTEMATIC, RS_STRATIFIED, RS_MULTINOMIAL = 1, 2, 3
 (BUILTIN_GENERIC, BUILTIN_SI, BUILTIN_SIR, BUILTIN_SEI, BUILTIN_SEIR, BUILTIN_SI_FD, BUILTIN_SIR_FD,
  BUILTIN_SEI_FD, BUILTIN_SEIR_FD, BUILTIN_LOTKA, BUILTIN_ROSSMAC) = range(11)
+BUILTIN_USER = 100
 DBG_LOGW, DBG_OFFSPRING_END = 1, 2
 
 
@@ -75,6 +76,8 @@ _PROTOTYPES = {
     "dpomp_version": (C.c_char_p, []),
     "dpomp_last_global_error": (C.c_char_p, []),
     "dpomp_create": (C.c_int, [C.POINTER(ModelDescC), C.c_int, C.POINTER(C.c_void_p)]),
+    "dpomp_create_with_source": (C.c_int, [C.POINTER(ModelDescC), C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "dpomp_check_rate_source": (C.c_int, [C.POINTER(ModelDescC), C.c_char_p, C.c_char_p, C.c_int64]),
     "dpomp_destroy": (None, [C.c_void_p]),
     "dpomp_last_error": (C.c_char_p, [C.c_void_p]),
     "dpomp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -11,7 +11,11 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
 #include "../../include/dpomp.h"
+#include "dpomp_embedded_sources.h"
 #include "dpomp_kernels.h"
 
 using namespace dpomp;
@@ -100,6 +104,10 @@ struct dpomp_handle {
     std::vector<long long> ysum;
     PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
+    // run-time compiled rate evaluator (dpomp_create_with_source)
+    bool rtc = false;
+    hipModule_t rtc_module = nullptr;
+    hipFunction_t rtc_prop1 = nullptr, rtc_propc = nullptr, rtc_sim = nullptr;
     int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
                         // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
@@ -220,6 +228,9 @@ int validate_desc(const dpomp_model_desc* d) {
         if (d->initial_condition[s] < 0 || d->initial_condition[s] >= ((int64_t)1 << 30))
             return fail(nullptr, DPOMP_EINVAL, "initial_condition[%d] out of 0..2^30", s);
     for (int e = 0; e < d->n_events; ++e) {
+        for (int s2 = 0; s2 < d->n_states; ++s2)
+            if (d->transition[e][s2] < -127 || d->transition[e][s2] > 127) return fail(nullptr, DPOMP_EINVAL, "transition[%d][%d] out of int8 range", e, s2);
+        if (d->builtin_id == DPOMP_BUILTIN_USER) continue;  // rates come from compiled source, not from the table
         const dpomp_rate_term& t = d->rate[e];
         if (t.theta_index < 0 || t.theta_index >= d->n_params) return fail(nullptr, DPOMP_EINVAL, "rate[%d].theta_index out of range", e);
         if (t.form != DPOMP_RATE_LEFT && t.form != DPOMP_RATE_RATIO) return fail(nullptr, DPOMP_EINVAL, "rate[%d].form unknown", e);
@@ -227,8 +238,6 @@ int validate_desc(const dpomp_model_desc* d) {
         for (int f = 0; f < t.n_factors; ++f)
             if (t.factor_mask[f] == 0 || (t.factor_mask[f] >> d->n_states)) return fail(nullptr, DPOMP_EINVAL, "rate[%d].factor_mask[%d] invalid", e, f);
         if (t.denom_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "rate[%d].denom_mask invalid", e);
-        for (int s = 0; s < d->n_states; ++s)
-            if (d->transition[e][s] < -127 || d->transition[e][s] > 127) return fail(nullptr, DPOMP_EINVAL, "transition[%d][%d] out of int8 range", e, s);
     }
     for (int t = 1; t < d->n_obs; ++t)
         if (d->obs_time[t] < d->obs_time[t - 1]) return fail(nullptr, DPOMP_EINVAL, "obs_time must be non-decreasing");
@@ -300,6 +309,8 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     return DPOMP_OK;
 }
 
+hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a);
+
 // The sequencer.  ymin/ymax 1-based as in the reference.
 int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, int ymax, uint64_t seed,
                 int64_t seg_base, uint32_t domain, double* out_ll, uint32_t* out_status,
@@ -360,10 +371,10 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             // taken by other waves); below that the plain kernel wins by 10-15 % (tools/latency_probe.py).
             int rpl = h->force_rpl;
             if (rpl == 0) rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves) ? kDefaultPropVariant : 1;
-            PropFn fn = rpl == 4 ? h->prop.q4 : rpl == 2 ? h->prop.q2 : rpl == 16 ? h->prop.c16 : rpl == 32 ? h->prop.c32 : h->prop.fn1;
+            if (h->rtc && rpl != 32) rpl = 1;  // run-time compiled models come in two variants
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
-            hipLaunchKernelGGL(fn, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, 0, st, a);
+            HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
         }
         if (record_states)
             HIPCHK(h, hipMemcpyAsync(record_states + (size_t)k * B * p->S * p->Pp, p->state[p->cur],
@@ -455,6 +466,113 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     return DPOMP_OK;
 }
 
+// ---- hipRTC: user rate functions --------------------------------------------------------------------------
+struct RtcApi {
+    void* lib = nullptr;
+    hiprtcResult (*create)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    hiprtcResult (*add_name)(hiprtcProgram, const char*) = nullptr;
+    hiprtcResult (*compile)(hiprtcProgram, int, const char* const*) = nullptr;
+    hiprtcResult (*log_size)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*get_log)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*lowered)(hiprtcProgram, const char*, const char**) = nullptr;
+    hiprtcResult (*code_size)(hiprtcProgram, size_t*) = nullptr;
+    hiprtcResult (*get_code)(hiprtcProgram, char*) = nullptr;
+    hiprtcResult (*destroy)(hiprtcProgram*) = nullptr;
+};
+
+RtcApi* rtc_api() {  // loaded on first use only: the library itself does not depend on hipRTC
+    static RtcApi api;
+    if (api.lib) return &api;
+    void* lib = nullptr;
+    for (const char* name : {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!lib) return nullptr;
+#define DPOMP_SYM(field, sym) *(void**)(&api.field) = dlsym(lib, sym)
+    DPOMP_SYM(create, "hiprtcCreateProgram");
+    DPOMP_SYM(add_name, "hiprtcAddNameExpression");
+    DPOMP_SYM(compile, "hiprtcCompileProgram");
+    DPOMP_SYM(log_size, "hiprtcGetProgramLogSize");
+    DPOMP_SYM(get_log, "hiprtcGetProgramLog");
+    DPOMP_SYM(lowered, "hiprtcGetLoweredName");
+    DPOMP_SYM(code_size, "hiprtcGetCodeSize");
+    DPOMP_SYM(get_code, "hiprtcGetCode");
+    DPOMP_SYM(destroy, "hiprtcDestroyProgram");
+#undef DPOMP_SYM
+    if (!api.create || !api.compile || !api.get_code || !api.lowered) return nullptr;
+    api.lib = lib;
+    return &api;
+}
+
+const char* const kRtcNames[3] = {"dpomp::k_propagate<dpomp::RUser>", "dpomp::k_propagate_c<dpomp::RUser, 32>",
+                                  "dpomp::k_simulate_rec<dpomp::RUser>"};
+
+// Compiles kernels + user source.  On success `code` holds the gfx950 code object and `lowered` the mangled names.
+int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<char>& code, std::string lowered[3],
+                std::string& log) {
+    RtcApi* api = rtc_api();
+    if (!api) {
+        log = "hipRTC (libhiprtc.so) could not be loaded";
+        return DPOMP_EDEVICE;
+    }
+    char head[512];
+    snprintf(head, sizeof head, "#include \"dpomp_kernels.h\"\nnamespace dpomp {\n#line 1 \"rate_source\"\n");
+    char tail[1024];
+    snprintf(tail, sizeof tail,
+             "\nstruct RUser : RBase<%d, %d> {\n  static __device__ __forceinline__ void rates(const DevModel&, const double* th, "
+             "const int (&x)[%d], double (&r)[%d]) { dpomp_user_rates(th, x, r); }\n};\n}  // namespace dpomp\n",
+             d->n_states, d->n_events, d->n_states, d->n_events);
+    const std::string src = std::string(head) + rate_source + tail;
+    const char* headers[3] = {kSrcKernels, kSrcNumerics, kSrcLogTable};
+    const char* names[3] = {"dpomp_kernels.h", "dpomp_numerics.h", "dpomp_log_table.h"};
+    hiprtcProgram prog;
+    if (api->create(&prog, src.c_str(), "dpomp_user_model.hip", 3, headers, names) != HIPRTC_SUCCESS) {
+        log = "hiprtcCreateProgram failed";
+        return DPOMP_EDEVICE;
+    }
+    for (const char* n : kRtcNames) api->add_name(prog, n);
+    const char* opts[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17"};
+    const hiprtcResult r = api->compile(prog, 4, opts);
+    size_t ls = 0;
+    if (api->log_size && api->log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        log.resize(ls);
+        api->get_log(prog, &log[0]);
+    }
+    int rc = DPOMP_OK;
+    if (r != HIPRTC_SUCCESS) {
+        if (log.empty()) log = "hiprtcCompileProgram failed";
+        rc = DPOMP_EINVAL;
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            const char* ln = nullptr;
+            if (api->lowered(prog, kRtcNames[i], &ln) != HIPRTC_SUCCESS || !ln) rc = DPOMP_EDEVICE;
+            else lowered[i] = ln;
+        }
+        size_t cs = 0;
+        if (rc == DPOMP_OK && api->code_size(prog, &cs) == HIPRTC_SUCCESS && cs) {
+            code.resize(cs);
+            if (api->get_code(prog, code.data()) != HIPRTC_SUCCESS) rc = DPOMP_EDEVICE;
+        } else if (rc == DPOMP_OK) {
+            rc = DPOMP_EDEVICE;
+        }
+    }
+    api->destroy(&prog);
+    return rc;
+}
+
+// One launch site for the propagation kernel: compiled-in template instance or run-time compiled module function.
+hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a) {
+    if (h->rtc) {
+        void* params[] = {&a};
+        return hipModuleLaunchKernel(variant == 32 ? h->rtc_propc : h->rtc_prop1, grid.x, grid.y, grid.z, block.x, block.y,
+                                     block.z, 0, st, params, nullptr);
+    }
+    PropFn fn = variant == 4 ? h->prop.q4 : variant == 2 ? h->prop.q2 : variant == 16 ? h->prop.c16 : variant == 32 ? h->prop.c32 : h->prop.fn1;
+    hipLaunchKernelGGL(fn, grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, dpomp_handle** out);
+
 }  // namespace
 
 extern "C" {
@@ -470,6 +588,39 @@ const char* dpomp_version(void) { return "dpomp-hip 0.1 (gfx950, abi 1)"; }
 const char* dpomp_last_global_error(void) { return g_global_error.c_str(); }
 
 int dpomp_create(const dpomp_model_desc* d, int device, dpomp_handle** out) {
+    if (d && d->builtin_id == DPOMP_BUILTIN_USER)
+        return fail(nullptr, DPOMP_EINVAL, "builtin_id DPOMP_BUILTIN_USER needs dpomp_create_with_source");
+    return create_impl(d, device, nullptr, out);
+}
+
+int dpomp_create_with_source(const dpomp_model_desc* d, int device, const char* rate_source, dpomp_handle** out) {
+    if (!rate_source) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
+    if (d && d->builtin_id != DPOMP_BUILTIN_USER)
+        return fail(nullptr, DPOMP_EINVAL, "dpomp_create_with_source needs builtin_id = DPOMP_BUILTIN_USER");
+    return create_impl(d, device, rate_source, out);
+}
+
+int dpomp_check_rate_source(const dpomp_model_desc* d, const char* rate_source, char* log, int64_t log_size) {
+    if (log && log_size > 0) log[0] = 0;
+    int rc = validate_desc(d);
+    if (rc != DPOMP_OK) return rc;
+    if (!rate_source) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
+    std::vector<char> code;
+    std::string lowered[3], text;
+    rc = rtc_compile(d, rate_source, code, lowered, text);
+    if (log && log_size > 0) {
+        strncpy(log, text.c_str(), (size_t)log_size - 1);
+        log[log_size - 1] = 0;
+    }
+    if (rc != DPOMP_OK) fail(nullptr, rc, "rate source does not compile: %.300s", text.c_str());
+    return rc;
+}
+
+}  // extern "C"
+
+namespace {
+
+int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, dpomp_handle** out) {
     if (!out) return fail(nullptr, DPOMP_EINVAL, "out is NULL");
     *out = nullptr;
     int rc = validate_desc(d);
@@ -521,7 +672,28 @@ int dpomp_create(const dpomp_model_desc* d, int device, dpomp_handle** out) {
     }
     for (const PropEntry& pe : kPropTable)
         if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
-    if (!h->prop.fn1) {
+    if (rate_source) {
+        std::vector<char> code;
+        std::string lowered[3], text;
+        rc = rtc_compile(d, rate_source, code, lowered, text);
+        if (rc != DPOMP_OK) {
+            rc = fail(nullptr, rc, "rate source does not compile: %.400s", text.c_str());
+            (void)hipStreamDestroy(h->own_stream);
+            delete h;
+            return rc;
+        }
+        hipError_t me = hipModuleLoadData(&h->rtc_module, code.data());
+        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_prop1, h->rtc_module, lowered[0].c_str());
+        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_propc, h->rtc_module, lowered[1].c_str());
+        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_sim, h->rtc_module, lowered[2].c_str());
+        if (me != hipSuccess) {
+            rc = fail(nullptr, DPOMP_EDEVICE, "loading the compiled rate module: %s", hipGetErrorString(me));
+            (void)hipStreamDestroy(h->own_stream);
+            delete h;
+            return rc;
+        }
+        h->rtc = true;
+    } else if (!h->prop.fn1) {
         h->prop = generic_set(d->n_states, d->n_events);
         h->prop_is_generic = true;
     }
@@ -530,9 +702,14 @@ int dpomp_create(const dpomp_model_desc* d, int device, dpomp_handle** out) {
     return DPOMP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 void dpomp_destroy(dpomp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->rtc_module) (void)hipModuleUnload(h->rtc_module);
     if (h->scratch_pop) pop_release(h->scratch_pop);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -744,8 +921,13 @@ int dpomp_simulate_events(dpomp_handle* h, const double* theta, int64_t P, uint6
         a.T = T;
         a.seg = (uint32_t)seg;
         a.seed = seed;
-        hipLaunchKernelGGL(h->prop.sim, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, a);
-        e = hipGetLastError();
+        if (h->rtc) {
+            void* params[] = {&a};
+            e = hipModuleLaunchKernel(h->rtc_sim, (unsigned)((P + kBlock - 1) / kBlock), 1, 1, kBlock, 1, 1, 0, h->stream, params, nullptr);
+        } else {
+            hipLaunchKernelGGL(h->prop.sim, dim3((unsigned)((P + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, a);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipMemcpyAsync(out_counts, d_counts, (size_t)P * 8, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(out_states, d_states, (size_t)T * S * P * 8, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(out_times, d_time, nev * 8, hipMemcpyDeviceToHost, h->stream);

@@ -12,14 +12,17 @@
 // segment, i.e. structure-of-arrays, so a wave reads 64 consecutive ints per component;
 // logw[b][p] double; offs[b][p] int32 (offspring boundaries N_j).
 #pragma once
+#if !defined(__HIPCC_RTC__)  // hipRTC (run-time compiled user rate functions) has these built in
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#include <type_traits>
+#endif
 
 #include "dpomp_numerics.h"
 
 namespace dpomp {
+
+template <bool C, class A, class B> struct cond_t { using type = A; };
+template <class A, class B> struct cond_t<false, A, B> { using type = B; };
 
 constexpr int kBlock = 256;        // threads per workgroup (4 waves of 64)
 constexpr int kItems = 4;          // slots per thread in the streaming kernels
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_init(DevModel m, int32_t* state, int
 template <class R>
 __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     constexpr int S = R::S, E = R::E;
-    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < a.P;
@@ -325,7 +328,7 @@ template <class R, int RPL>
 __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     constexpr int S = R::S, E = R::E;
     constexpr int C = kBlock * RPL;
-    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     __shared__ double s_log[128][2];
     __shared__ int32_t s_x[S][C];
     __shared__ uint4 s_seed[C];
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
 template <class R, int CHK>
 __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     constexpr int S = R::S, E = R::E;
-    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     __shared__ double s_log[128][2];
     __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
     __shared__ int32_t s_cnt[kBlock];     // executed events, bit 31 = event cap
@@ -667,7 +670,7 @@ struct SimArgs {
 template <class R>
 __global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
     constexpr int S = R::S, E = R::E;
-    using TW = typename std::conditional<(S <= 4), uint32_t, uint64_t>::type;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= a.P) return;
     const int s_real = R::kGeneric ? a.m.S : S;

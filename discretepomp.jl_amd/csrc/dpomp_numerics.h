@@ -6,9 +6,18 @@
 // the same spec gives the same bits.  Compiles for gfx950 (hipcc) and, for the
 // host-side bit check in tests/test_numerics_host.py, as plain C++.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#else  // hipRTC has no <stdint.h>; same widths as the host's types, so kernel-argument structs keep their layout
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define DPOMP_HD __host__ __device__ __forceinline__
 #define DPOMP_D __device__ __forceinline__
 #define DPOMP_TABLE_QUAL static __device__ const

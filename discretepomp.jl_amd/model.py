@@ -166,6 +166,27 @@ class RateFunction:
         return output
 
 
+class RateSource:
+    """A rate function given as HIP C++ source, compiled at run time (hipRTC) into the propagation kernel --
+    for models the :class:`RateTerm` table cannot express.  The text must define
+
+        __device__ void dpomp_user_rates(const double* theta, const int* x, double* r);
+
+    (0-based ``theta[K]``, state ``x[S]``, write the ``E`` un-cumulated rates to ``r``).  ``host`` is an optional
+    Python callable with the reference's signature ``f(output, parameters, population)`` for host-side use."""
+
+    builtin_id = _abi.BUILTIN_USER
+    terms: list = []
+
+    def __init__(self, source: str, n_events: int, n_params: int, host: Optional[Callable] = None, name: str = "user_rf"):
+        self.source, self.n_events, self.n_params, self.host, self.name = source, int(n_events), int(n_params), host, name
+
+    def __call__(self, output, parameters, population):
+        if self.host is None:
+            raise NotImplementedError("this RateSource has no host implementation (pass host=...)")
+        return self.host(output, parameters, population)
+
+
 # --------------------------------------------------------------------------------------
 # Observation model and prior
 # --------------------------------------------------------------------------------------
@@ -229,7 +250,7 @@ def generate_weak_prior(n: int, b: float = 1.0) -> UniformProductPrior:
 class DPOMPModel:
     """Mirror of the reference's public model struct (hmm_structs.jl:107-116)."""
     model_name: str
-    rate_function: RateFunction
+    rate_function: "RateFunction | RateSource"
     initial_condition: List[int]
     m_transition: np.ndarray  # E x S
     obs_function: Callable = dmy_obs_fn
@@ -315,7 +336,7 @@ def generate_custom_model(model_name: str, rate_function, initial_condition, m_t
                           t0_index: int = 0):
     """``generate_custom_model`` (hmm_examples.jl:237-239).  ``rate_function`` is a
     :class:`RateFunction` or a list of :class:`RateTerm`."""
-    if not isinstance(rate_function, RateFunction):
+    if not isinstance(rate_function, (RateFunction, RateSource)):
         rate_function = RateFunction(rate_function)
     m_transition = np.asarray(m_transition, dtype=np.int64)
     if obs_model is None:
@@ -357,9 +378,12 @@ class ModelDescriptor:
         d.t0_index = int(model.t0_index)
         for s in range(S):
             d.initial_condition[s] = model.initial_condition[s]
+        self.rate_source = model.rate_function.source if isinstance(model.rate_function, RateSource) else None
         for e in range(E):
             for s in range(S):
                 d.transition[e][s] = int(model.m_transition[e, s])
+            if self.rate_source is not None:
+                continue
             t = model.rate_function.terms[e]
             d.rate[e].theta_index = t.theta - 1
             d.rate[e].form = _abi.RATE_LEFT if t.form == "left" else _abi.RATE_RATIO

@@ -125,7 +125,11 @@ class ParticleFilter:
         self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic)
         self.n_states, self.n_params, self.n_obs = self.desc.n_states, self.desc.n_params, self.desc.n_obs
         self.essc = essc  # accepted and unused, as in the reference (src/hmm_particle_filter.jl:63-68)
-        rc = self._lib.dpomp_create(self.desc.byref(), int(device), C.byref(self._h))
+        if self.desc.rate_source is not None:  # arbitrary rate code: compiled with hipRTC into the kernels
+            rc = self._lib.dpomp_create_with_source(self.desc.byref(), int(device), self.desc.rate_source.encode(),
+                                                    C.byref(self._h))
+        else:
+            rc = self._lib.dpomp_create(self.desc.byref(), int(device), C.byref(self._h))
         if rc != _abi.OK:
             self._h = C.c_void_p()
             raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
@@ -247,6 +251,20 @@ class ParticleFilter:
         u, lg, ex = np.empty(n), np.empty(n), np.empty(n)
         self._check(self._lib.dpomp_selftest_numerics(self._h, n, int(seed), _dptr(x), _dptr(u), _dptr(lg), _dptr(ex)))
         return u, lg, ex
+
+
+def check_rate_source(model: DPOMPModel, obs_data: Sequence[Observation]) -> str:
+    """Compile-only check of a :class:`RateSource` model (needs no GPU).  Returns the compiler log; raises
+    :class:`DpompError` with the diagnostics if the source does not compile."""
+    lib = _abi.load_library()
+    desc = ModelDescriptor(model, obs_data)
+    if desc.rate_source is None:
+        raise TypeError("model.rate_function is not a RateSource")
+    log = C.create_string_buffer(1 << 16)
+    rc = lib.dpomp_check_rate_source(desc.byref(), desc.rate_source.encode(), log, len(log))
+    if rc != _abi.OK:
+        raise DpompError(rc, log.value.decode(errors="replace") or lib.dpomp_last_global_error().decode())
+    return log.value.decode(errors="replace")
 
 
 def get_particle_filter_lpdf(model: DPOMPModel, obs_data: Sequence[Observation], np: int = C_DF_PF_P,

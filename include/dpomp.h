@@ -95,6 +95,8 @@ extern "C" {
 #define DPOMP_BUILTIN_SEIR_FD 8  /* seir_rf_fd   :140-144                */
 #define DPOMP_BUILTIN_LOTKA 9    /* lotka_rf     :149-154                */
 #define DPOMP_BUILTIN_ROSSMAC 10 /* rossmac_rf   :159-168                */
+#define DPOMP_BUILTIN_USER 100   /* rates come from source text compiled at run time (dpomp_create_with_source);
+                                    `rate[]` is ignored */
 
 /* One event rate:  see DPOMP_RATE_*.  f_i = sum of the state components whose bit is
  * set in factor_mask[i] (computed in integers, then promoted to double as Julia does);
@@ -146,6 +148,15 @@ const char* dpomp_version(void);
 const char* dpomp_last_global_error(void);
 
 int dpomp_create(const dpomp_model_desc* desc, int device, dpomp_handle** out);
+/* A model whose rate function is arbitrary device code -- the closest thing to the reference's
+ * `rate_function::Function` closure (hmm_structs.jl:109).  `rate_source` is HIP C++ that defines
+ *     __device__ void dpomp_user_rates(const double* theta, const int* x, double* r);
+ * writing the E (un-cumulated) event rates for parameter vector theta[K] and state x[S].  It is compiled with
+ * hipRTC for gfx950 together with the library's kernels (-ffp-contract=off: results stay reproducible by the
+ * same source compiled for the host).  desc->builtin_id must be DPOMP_BUILTIN_USER. */
+int dpomp_create_with_source(const dpomp_model_desc* desc, int device, const char* rate_source, dpomp_handle** out);
+/* Compile-only check of a rate source (needs no GPU); the compiler log is copied into log[log_size]. */
+int dpomp_check_rate_source(const dpomp_model_desc* desc, const char* rate_source, char* log, int64_t log_size);
 void dpomp_destroy(dpomp_handle* h);
 const char* dpomp_last_error(const dpomp_handle* h);
 /* Run the kernels on an existing HIP stream (hipStream_t passed as void*); NULL = the

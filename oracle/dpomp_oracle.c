@@ -185,7 +185,19 @@ static inline int64_t mask_sum(uint32_t mask, const int64_t* x, int S) {
  * operand to Float64 as the left-associated product proceeds (DPOMP_RATE_LEFT);
  * rossmac_rf :165-166 multiplies two integers first and divides Int/Int -> Float64
  * (DPOMP_RATE_RATIO). */
+typedef void (*orc_user_rates_fn)(const double* theta, const int* x, double* r);
+static orc_user_rates_fn g_user_rates = 0;
+/* Host twin of a run-time compiled rate source (DPOMP_BUILTIN_USER): tests compile the SAME source text for
+ * the CPU (g++ -ffp-contract=off) and register it here, so user rate code is checked like the built-ins. */
+void orc_set_user_rates(orc_user_rates_fn fn) { g_user_rates = fn; }
+
 void orc_rates(const dpomp_model_desc* d, const double* theta, const int64_t* x, double* rates) {
+    if (d->builtin_id == DPOMP_BUILTIN_USER && g_user_rates) {
+        int xi[DPOMP_MAX_STATES];
+        for (int i = 0; i < d->n_states; ++i) xi[i] = (int)x[i];
+        g_user_rates(theta, xi, rates);
+        return;
+    }
     for (int e = 0; e < d->n_events; ++e) {
         const dpomp_rate_term* t = &d->rate[e];
         double th = theta[t->theta_index];

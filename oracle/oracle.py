@@ -65,6 +65,7 @@ def lib():
         L.orc_simulate_events.restype = C.c_int64
         L.orc_simulate_events.argtypes = [C.c_void_p, dp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, dp,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.orc_set_user_rates.argtypes = [C.c_void_p]
         L.orc_simulate.argtypes = [C.c_void_p, C.c_int64, dp, C.c_uint64, C.c_uint32, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -178,6 +179,24 @@ def simulate_events(desc, theta, seed=1, seg=0, p=0, max_events=196000):
                                   types.ctypes.data_as(C.POINTER(C.c_int32)), _ip(states))
     m = max_events if n < 0 else n
     return n, times[:m].copy(), types[:m].copy(), states
+
+
+_user_libs = []
+
+
+def set_user_rates_from_source(source: str, workdir: str):
+    """Compile a rate source (the text handed to dpomp_create_with_source) for the host and register it as the
+    oracle's rate function for DPOMP_BUILTIN_USER models."""
+    src = os.path.join(workdir, "user_rates.cpp")
+    so = os.path.join(workdir, f"libuser_rates_{len(_user_libs)}.so")
+    with open(src, "w") as f:
+        f.write('#include <cmath>\n#define __device__\n#define __forceinline__ inline\n' + source +
+                '\nextern "C" void orc_user_rates_entry(const double* th, const int* x, double* r) { dpomp_user_rates(th, x, r); }\n')
+    fma = ["-mfma"] if " fma" in open("/proc/cpuinfo").read() else []
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", *fma, "-fPIC", "-shared", "-o", so, src])
+    ul = C.CDLL(so)
+    _user_libs.append(ul)
+    lib().orc_set_user_rates(C.cast(ul.orc_user_rates_entry, C.c_void_p))
 
 
 def max_threads():

@@ -1,0 +1,78 @@
+"""Run-time compiled rate functions (hipRTC): the pluggable on-device rate evaluator for models outside the
+RateTerm table -- the counterpart of the reference's arbitrary `rate_function` closure (hmm_structs.jl:109)."""
+import numpy as np
+import pytest
+
+# SIS with saturating incidence and an immigration term: neither fits ((theta*f0)*f1)/d nor theta*((f0*f1)/d)
+SOURCE = """
+__device__ void dpomp_user_rates(const double* theta, const int* x, double* r) {
+    const double S = (double)x[0], I = (double)x[1];
+    r[0] = theta[0] * S * I / (1.0 + theta[2] * I) + theta[3];   // infection, saturating in I, plus import
+    r[1] = theta[1] * I;                                          // recovery
+}
+"""
+
+
+def _host(out, th, x):
+    out[0] = th[0] * x[0] * x[1] / (1.0 + th[2] * x[1]) + th[3]
+    out[1] = th[1] * x[1]
+    return out
+
+
+def _model(dp):
+    rf = dp.RateSource(SOURCE, n_events=2, n_params=4, host=_host)
+    # (the reference's default prior has one dimension per event -- generate_weak_prior(size(m_transition, 1)),
+    #  hmm_examples.jl:237 -- this model has four parameters)
+    return dp.generate_custom_model("SIS-sat", rf, [100, 1], [[-1, 1], [1, -1]], prior=dp.generate_weak_prior(4))
+
+
+def test_rate_source_compiles_without_a_gpu(dp, pooley):
+    log = dp.check_rate_source(_model(dp), pooley)
+    assert "error" not in log.lower()
+    d = dp.ModelDescriptor(_model(dp), pooley)
+    assert d.c.builtin_id == 100 and d.n_params == 4
+
+
+def test_broken_rate_source_reports_the_compiler_diagnostics(dp, pooley):
+    bad = dp.RateSource("__device__ void dpomp_user_rates(const double* theta, const int* x, double* r) { r[0] = undefined_symbol; }",
+                        n_events=2, n_params=2)
+    model = dp.generate_custom_model("bad", bad, [100, 1], [[-1, 1], [1, -1]])
+    with pytest.raises(dp.DpompError) as ei:
+        dp.check_rate_source(model, pooley)
+    assert "undefined_symbol" in str(ei.value) and "rate_source" in str(ei.value)   # line numbers refer to the user's text
+
+
+def test_oracle_runs_the_same_source_on_the_host(dp, orc, pooley, tmp_path):
+    orc.set_user_rates_from_source(SOURCE, str(tmp_path))
+    desc = dp.ModelDescriptor(_model(dp), pooley)
+    th, x = [0.003, 0.1, 0.01, 0.02], [90, 11]
+    assert np.array_equal(orc.rates(desc, th, x), _host(np.zeros(2), th, x))
+    r = orc.pf_loglik(desc, 512, th, seed=3)
+    assert np.isfinite(r.ll) and r.events > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 32])
+def test_rate_source_filter_matches_oracle(dp, orc, pooley, tmp_path, variant):
+    orc.set_user_rates_from_source(SOURCE, str(tmp_path))
+    pf = dp.ParticleFilter(_model(dp), pooley)
+    pf.set_propagate_variant(variant)
+    theta = np.array([[0.003, 0.0035], [0.1, 0.12], [0.01, 0.02], [0.02, 0.0]])
+    pop = pf.alloc_population(2, 3000)
+    ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=13)
+    for b in range(2):
+        ref = orc.pf_loglik(pf.desc, 3000, theta[:, b], seed=13, seg=b)
+        assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
+    assert pf.last_event_count() == sum(orc.pf_loglik(pf.desc, 3000, theta[:, b], seed=13, seg=b).events for b in range(2))
+    pf.close()
+
+
+@pytest.mark.gpu
+def test_rate_source_simulation_matches_oracle(dp, orc, tmp_path):
+    orc.set_user_rates_from_source(SOURCE, str(tmp_path))
+    model = _model(dp)
+    res = dp.gillespie_sim(model, [0.003, 0.1, 0.01, 0.02], n_sims=2, seed=5, verbose=False)
+    desc = dp.ModelDescriptor(model, dp.generate_observations(100.0, 5, 2))
+    for i, r in enumerate(res):
+        n, times, types, states = orc.simulate_events(desc, [0.003, 0.1, 0.01, 0.02], seed=5, p=i)
+        assert [e.time for e in r.particle.trajectory] == list(times) and r.particle.final_condition == list(states[-1])
