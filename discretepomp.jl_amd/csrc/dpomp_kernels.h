@@ -1,11 +1,17 @@
 // dpomp_kernels.h -- gfx950 kernels of the bootstrap particle filter.
 //
-//   k_propagate   iterate_particles!   src/hmm_particle_filter.jl:9-33  (+ choose_event
-//                 src/hmm_cmn.jl:4-10, rate functions src/hmm_examples.jl:103-168,
-//                 transition src/hmm_examples.jl:11-16, obs model :59-67)
+//   k_propagate / k_propagate_c / k_propagate_q
+//                 iterate_particles!   src/hmm_particle_filter.jl:9-33  (+ choose_event src/hmm_cmn.jl:4-10,
+//                 rate functions src/hmm_examples.jl:103-168, transition :11-16, obs model :59-67);
+//                 three schedules of the same arithmetic: one particle per lane, + workgroup compaction
+//                 (default for chip-filling launches), LDS queue with lane refill
 //   k_wsum, k_scan_blocks, k_offsets, k_gather
-//                 log mean weight  src/hmm_particle_filter.jl:60  and
-//                 rsp_systematic   src/hmm_pf_resample.jl:24-42
+//                 log mean weight  src/hmm_particle_filter.jl:60  and rsp_systematic  src/hmm_pf_resample.jl:24-42
+//   k_gather_pos  rsp_stratified / rsp_multinomial (documented intent)  src/hmm_pf_resample.jl:46-63, :5-20
+//   k_simulate_rec  gillespie_sim with the Event history  src/hmm_sim.jl:55-102
+//   k_init, k_copy_segments, k_take_segments   population bookkeeping (hmm_particle_filter.jl:42-44, hmm_ibis.jl:71-75, :109)
+//
+// The file also compiles under hipRTC (__HIPCC_RTC__) together with a user-supplied rate function.
 //
 // Layout in HBM (per population handle): state[b][s][p] int32, p fastest, row stride Pp
 // (P rounded up to the 1024-slot tile) -- the reference's column-major P x S matrix per
