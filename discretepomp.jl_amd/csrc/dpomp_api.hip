@@ -3,6 +3,7 @@
 // over a device-resident population; no host synchronisation inside a call).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -112,6 +113,7 @@ struct dpomp_handle {
                         // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
     bool profiling = false;
+    double null_bracket_ms = 0.0;
     KernelStat stats[KID_COUNT];
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -986,6 +988,40 @@ int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const dou
 int dpomp_set_profiling(dpomp_handle* h, int on) {
     if (!h) return DPOMP_EINVAL;
     h->profiling = on != 0;
+    if (on && h->null_bracket_ms == 0.0) {  // calibrate the bracket itself once
+        HIPCHK(h, hipSetDevice(h->device));
+        // 64 empty brackets enqueued back to back behind a kernel (a busy queue, as in a filter call), one
+        // synchronisation at the end: per-bracket elapsed = what the two markers themselves cost.
+        std::vector<float> v;
+        const int n = 64;
+        std::vector<hipEvent_t> ev(2 * n);
+        for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+        int32_t* scratch = nullptr;
+        HIPCHK(h, hipMalloc((void**)&scratch, (size_t)kTile * 64 * 4));
+        for (int i = 0; i < n; ++i) {
+            // filler: S rows of 8 tiles each (S <= 8 -> at most 64 tiles = the scratch size), 16-B aligned rows
+            hipLaunchKernelGGL(k_init, dim3(8, 1), dim3(kBlock), 0, h->stream, h->dm, scratch, (int64_t)kTile * 8);
+            (void)hipEventRecord(ev[2 * i], h->stream);
+            (void)hipEventRecord(ev[2 * i + 1], h->stream);
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) == hipSuccess) v.push_back(ms);
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        (void)hipFree(scratch);
+        if (!v.empty()) {
+            std::sort(v.begin(), v.end());
+            h->null_bracket_ms = v[v.size() / 2];
+        }
+    }
+    return DPOMP_OK;
+}
+
+int dpomp_get_null_bracket_ms(dpomp_handle* h, double* ms) {
+    if (!h || !ms) return DPOMP_EINVAL;
+    *ms = h->null_bracket_ms;
     return DPOMP_OK;
 }
 

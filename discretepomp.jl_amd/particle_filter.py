@@ -237,6 +237,12 @@ class ParticleFilter:
     def set_profiling(self, on: bool):
         self._check(self._lib.dpomp_set_profiling(self._h, 1 if on else 0))
 
+    def null_bracket_us(self) -> float:
+        """Median elapsed time of an empty HIP-event bracket (what profiling adds to each kernel's duration)."""
+        ms = C.c_double()
+        self._check(self._lib.dpomp_get_null_bracket_ms(self._h, C.byref(ms)))
+        return float(ms.value) * 1e3
+
     def kernel_stats(self) -> dict:
         out = {}
         for kid in range(self._lib.dpomp_kernel_count()):

@@ -233,6 +233,9 @@ int dpomp_set_profiling(dpomp_handle* h, int on);
 int dpomp_kernel_count(void);
 const char* dpomp_kernel_name(int kernel_id);
 int dpomp_get_kernel_stat(dpomp_handle* h, int kernel_id, int64_t* launches, double* total_ms);
+/* Elapsed time of an EMPTY event bracket (two hipEventRecord with nothing between), median of 64, measured when
+ * profiling was switched on: what every bracket adds to a kernel's own duration. */
+int dpomp_get_null_bracket_ms(dpomp_handle* h, double* ms);
 /* Gillespie events executed by the last pf call (sum over all particles). */
 int dpomp_last_event_count(dpomp_handle* h, uint64_t* events);
 
