@@ -390,3 +390,20 @@ def test_maximum_model_size_through_the_generic_evaluator(dp, orc, make_obs):
     # host evaluation of the same table agrees with the oracle's interpreter
     assert np.array_equal(model.rate_function(np.zeros(8), theta, x0), orc.rates(pf.desc, theta, x0))
     pf.close()
+
+
+@pytest.mark.parametrize("rs_type", [1, 2])
+def test_three_million_particles_unfused_scan_path(dp, orc, make_obs, rs_type):
+    """P = 3 * 2^20 (3072 tiles > 2048): the tile-sum scan runs as its own kernel and k_offsets<false> consumes its
+    prefixes.  Low rates keep the oracle fast (~0.3 events per particle and interval); parity stays bit-exact."""
+    y = make_obs([1.0, 2.0, 3.0], [[0, 1], [0, 2], [0, 1]])
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), y, rs_type=rs_type)
+    P = 3 * (1 << 20) + 17
+    theta = [0.003, 0.2]
+    pop = pf.alloc_population(1, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, 3, seed=4)
+    ref = orc.pf_loglik(pf.desc, P, theta, seed=4, rs_type=rs_type, nthreads=8)
+    assert ll[0] == ref.ll
+    assert np.array_equal(pop.download(0), ref.pop)
+    assert pf.last_event_count() == ref.events
+    pf.close()
