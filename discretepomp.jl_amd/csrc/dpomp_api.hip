@@ -136,6 +136,7 @@ struct dpomp_pop {
     int32_t* tile_end = nullptr;           // [B][nblk]
     double* posw = nullptr;                // [B][Pp]   (allocated on first use of resampler 2 / 3)
     double* tile_end_pos = nullptr;        // [B][nblk]
+    double* rsu = nullptr;                 // [B]
     char* ctl = nullptr;                   // control block, see pop_alloc_impl
     size_t ctl_bytes = 0, ctl_result_bytes = 0;
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
@@ -256,6 +257,7 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->tile_end);
     (void)hipFree(p->posw);
     (void)hipFree(p->tile_end_pos);
+    (void)hipFree(p->rsu);
     (void)hipFree(p->ctl);
     (void)hipFree(p->wtot);
     (void)hipFree(p->theta);
@@ -291,6 +293,7 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->tile_end, (size_t)B * p->nblk * 4);
+    DPOMP_ALLOC(p->rsu, (size_t)B * 8);
     // one control block: [ll B f64][events u64][status B u32, padded to 8 B][segmax T*B u64] -> one memset and one
     // result download per call
     {
@@ -395,6 +398,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.tile_end = p->tile_end;
             w.posw = p->posw;
             w.tile_end_pos = p->tile_end_pos;
+            w.rsu = p->rsu;
             w.rs_type = h->rs_type;
             w.Pp = p->Pp;
             w.P = (int32_t)p->P;

@@ -741,6 +741,7 @@ struct WeightArgs {
     int32_t* tile_end;                  // [B][nblk] first_parent: parent tile of the first slot of each output tile
     double* posw;                       // [B][Pp]   pos_j = c_j / W * P (stratified / multinomial resamplers)
     double* tile_end_pos;               // [B][nblk] pos of the last particle of each tile
+    double* rsu;                        // [B] the systematic-resampling uniform of this observation (from k_wsum)
     int64_t Pp;
     int32_t rs_type;                    // DPOMP_RS_*
     int32_t P, nblk, sh;
@@ -770,8 +771,13 @@ __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         a.blocksum[(int64_t)b * a.nblk + blk] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (blk == 0) {  // rand() of hmm_pf_resample.jl:27, once per segment instead of once per thread of k_offsets
+            Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
+            a.rsu[b] = u01(stream_next(rs));
+        }
+    }
 }
 
 // k_scan_blocks: one workgroup per segment; exclusive scan of the tile sums, the total W, and
@@ -866,8 +872,7 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     unsigned long long base = tile_prefix + (incl - c[kItems - 1]);
     for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
 
-    Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
-    const double r = u01(stream_next(rs));  // rand() of hmm_pf_resample.jl:27
+    const double r = a.rsu[b];  // rand() of hmm_pf_resample.jl:27 (drawn in k_wsum)
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
     if (a.rs_type == 1) {
         int n[kItems];
