@@ -82,6 +82,7 @@ _PROTOTYPES = {
     "dpomp_last_error": (C.c_char_p, [C.c_void_p]),
     "dpomp_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dpomp_set_resampler": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpomp_set_ess_threshold": (C.c_int, [C.c_void_p, C.c_double]),
     "dpomp_set_propagate_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dpomp_pf_loglik": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
                                   C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

@@ -112,6 +112,7 @@ struct dpomp_handle {
     int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
                         // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
+    double ess_frac = 0.0;  // > 0: ESS-adaptive resampling (dpomp_set_ess_threshold)
     bool profiling = false;
     double null_bracket_ms = 0.0;
     KernelStat stats[KID_COUNT];
@@ -137,6 +138,12 @@ struct dpomp_pop {
     double* posw = nullptr;                // [B][Pp]   (allocated on first use of resampler 2 / 3)
     double* tile_end_pos = nullptr;        // [B][nblk]
     double* rsu = nullptr;                 // [B]
+    // ESS-adaptive mode (allocated on first use)
+    unsigned long long* blocksum2 = nullptr;  // [B][nblk][2]
+    int32_t* carry[2] = {nullptr, nullptr};   // [B] ping-pong: weights carried into the next weighted observation
+    double* lprev[2] = {nullptr, nullptr};    // [B]
+    int32_t* noresample = nullptr;            // [B]
+    int carry_cur = 0;
     char* ctl = nullptr;                   // control block, see pop_alloc_impl
     size_t ctl_bytes = 0, ctl_result_bytes = 0;
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
@@ -258,6 +265,12 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->posw);
     (void)hipFree(p->tile_end_pos);
     (void)hipFree(p->rsu);
+    (void)hipFree(p->blocksum2);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(p->carry[i]);
+        (void)hipFree(p->lprev[i]);
+    }
+    (void)hipFree(p->noresample);
     (void)hipFree(p->ctl);
     (void)hipFree(p->wtot);
     (void)hipFree(p->theta);
@@ -338,6 +351,17 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     const dim3 block(kBlock);
     const dim3 grid_tiles((unsigned)p->nblk, (unsigned)B);
 
+    const bool adaptive = h->ess_frac > 0.0 && domain == DOMAIN_PROPAGATE;
+    if (adaptive && !p->blocksum2) {
+        HIPCHK(h, hipMalloc((void**)&p->blocksum2, (size_t)B * p->nblk * 16));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(h, hipMalloc((void**)&p->carry[i], (size_t)B * 4));
+            HIPCHK(h, hipMalloc((void**)&p->lprev[i], (size_t)B * 8));
+            HIPCHK(h, hipMemsetAsync(p->carry[i], 0, (size_t)B * 4, st));
+        }
+        HIPCHK(h, hipMalloc((void**)&p->noresample, (size_t)B * 4));
+    }
+    if (adaptive && ymin == 1) HIPCHK(h, hipMemsetAsync(p->carry[p->carry_cur], 0, (size_t)B * 4, st));
     HIPCHK(h, hipMemcpyAsync(p->theta, theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(p->ctl, 0, p->ctl_bytes, st));
 
@@ -370,6 +394,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.ysum = h->ysum[k];
         a.use_theta_t0 = (obs_i == 1 && h->dm.t0_index > 0) ? 1 : 0;
         a.want_weight = weighted ? 1 : 0;
+        a.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
             // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
@@ -399,6 +424,15 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.posw = p->posw;
             w.tile_end_pos = p->tile_end_pos;
             w.rsu = p->rsu;
+            w.ess_frac = adaptive ? h->ess_frac : 0.0;
+            w.blocksum2 = p->blocksum2;
+            w.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
+            w.lprev_in = adaptive ? p->lprev[p->carry_cur] : nullptr;
+            w.carry_out = adaptive ? p->carry[p->carry_cur ^ 1] : nullptr;
+            w.lprev_out = adaptive ? p->lprev[p->carry_cur ^ 1] : nullptr;
+            w.noresample = adaptive ? p->noresample : nullptr;
+            w.last_obs = obs_i == T ? 1 : 0;
+            if (adaptive) p->carry_cur ^= 1;  // the kernels below write the new carry state, the next observation reads it
             w.rs_type = h->rs_type;
             w.Pp = p->Pp;
             w.P = (int32_t)p->P;
@@ -434,6 +468,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                     gp.S = p->S;
                     gp.nblk = p->nblk;
                     gp.rs_type = h->rs_type;
+                    gp.noresample = adaptive ? p->noresample : nullptr;
                     gp.obs_k = (uint32_t)k;
                     gp.seg_base = (uint32_t)seg_base;
                     gp.seed = seed;
@@ -448,6 +483,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                 g.dst = p->state[p->cur ^ 1];
                 g.offs = p->offs;
                 g.first_parent = p->tile_end;
+                g.noresample = adaptive ? p->noresample : nullptr;
                 g.Pp = p->Pp;
                 g.P = (int32_t)p->P;
                 g.S = p->S;
@@ -734,6 +770,13 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type) {
     if (!h) return DPOMP_EINVAL;
     if (rs_type < DPOMP_RS_SYSTEMATIC || rs_type > DPOMP_RS_MULTINOMIAL) return fail(h, DPOMP_EINVAL, "rs_type %d unknown", rs_type);
     h->rs_type = rs_type;
+    return DPOMP_OK;
+}
+
+int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac) {
+    if (!h) return DPOMP_EINVAL;
+    if (!(ess_frac >= 0.0) || ess_frac > 1.0e6) return fail(h, DPOMP_EINVAL, "ess threshold must be >= 0 (0 = resample at every observation)");
+    h->ess_frac = ess_frac;
     return DPOMP_OK;
 }
 

@@ -66,6 +66,7 @@ struct PropArgs {
     long long ysum;
     int32_t use_theta_t0;  // first interval of a ymin == 1 call with t0_index > 0
     int32_t want_weight;
+    const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
 };
 
 // ---- rate evaluators (the pluggable part) -------------------------------------------------
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
                 if (a.m.obs_state_mask & (1u << s)) xs += x[s];
             const long long d = a.ysum - (long long)xs;
             g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
             if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
             a.logw[(int64_t)b * a.Pp + p] = g;
         }
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
             if (a.want_weight) {
                 const long long d = a.ysum - (long long)xs;
                 double g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+                if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
                 if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
                 a.logw[(int64_t)b * a.Pp + p] = g;
                 gmax = fmax(gmax, g);
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
         if (a.want_weight) {
             const long long d = a.ysum - (long long)xs;
             g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
             if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
             a.logw[(int64_t)b * a.Pp + p] = g;
         }
@@ -742,6 +746,15 @@ struct WeightArgs {
     double* posw;                       // [B][Pp]   pos_j = c_j / W * P (stratified / multinomial resamplers)
     double* tile_end_pos;               // [B][nblk] pos of the last particle of each tile
     double* rsu;                        // [B] the systematic-resampling uniform of this observation (from k_wsum)
+    // ESS-adaptive mode (ess_frac > 0; otherwise all unused)
+    double ess_frac;
+    unsigned long long* blocksum2;      // [B][nblk][2] per-tile sum of w^2 (hi, lo)
+    const int32_t* carry_in;            // [B] weights of this observation include carried ones
+    const double* lprev_in;             // [B] log sum exp of the carried log-weights
+    int32_t* carry_out;                 // [B]
+    double* lprev_out;                  // [B]
+    int32_t* noresample;                // [B] 1 = keep the population at this observation (gathers copy identically)
+    int32_t last_obs;                   // no resampling after the last observation of the data set
     int64_t Pp;
     int32_t rs_type;                    // DPOMP_RS_*
     int32_t P, nblk, sh;
@@ -761,18 +774,70 @@ __device__ __forceinline__ void load_tile_weights(const WeightArgs& a, int b, in
     for (int q = 0; q < kItems; ++q) w[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
 }
 
+__device__ __forceinline__ void add128(unsigned long long& hi, unsigned long long& lo, unsigned long long h,
+                                       unsigned long long l) {
+    const unsigned long long nl = lo + l;
+    hi += h + (nl < l ? 1ull : 0ull);
+    lo = nl;
+}
+__device__ __forceinline__ void wave_sum128(unsigned long long& hi, unsigned long long& lo) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long h = __shfl_xor(hi, off, 64), l = __shfl_xor(lo, off, 64);
+        add128(hi, lo, h, l);
+    }
+}
+
+// Closes one weighted observation of one segment: log-likelihood increment (hmm_particle_filter.jl:60, or
+// LSE(t) - LSE(a) when weights were carried) and, in the ESS-adaptive mode, the carry state for the next one.
+__device__ __forceinline__ void finish_segment(const WeightArgs& a, int b, unsigned long long W, bool resample) {
+    a.wtot[b] = W;
+    const bool carried = a.ess_frac > 0.0 && a.carry_in[b] != 0;
+    double lk = 0.0;
+    if (W == 0) {
+        a.ll[b] += -__builtin_inf();
+        atomicOr(&a.status[b], 2u /* DPOMP_ST_ZERO_WEIGHT */);
+    } else {
+        const double m = ordered_value(a.segmax[b]);
+        lk = log_sum_weight(m, W, a.sh);
+        a.ll[b] += carried ? lk - a.lprev_in[b] : log_mean_weight(m, W, a.sh, a.P);
+    }
+    if (a.ess_frac > 0.0) {
+        const bool keep = !a.last_obs && !resample;
+        a.carry_out[b] = keep ? 1 : 0;
+        a.lprev_out[b] = lk;
+        a.noresample[b] = keep ? 1 : 0;
+    }
+}
+
 // k_wsum: per-tile sum of the fixed-point weights rint(exp(g - max) 2^sh).
 __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     const int b = blockIdx.y, blk = blockIdx.x;
     unsigned long long w[kItems];
     load_tile_weights(a, b, blk, w);
     unsigned long long t = (w[0] + w[1]) + (w[2] + w[3]);
-    __shared__ unsigned long long s_sum[kBlock / 64];
+    __shared__ unsigned long long s_sum[kBlock / 64], s_hi[kBlock / 64], s_lo[kBlock / 64];
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = t;
+    if (a.ess_frac > 0.0) {  // sum of squares, exact in 128 bits (w < 2^53)
+        unsigned long long hi = 0, lo = 0;
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) add128(hi, lo, __umul64hi(w[q], w[q]), w[q] * w[q]);
+        wave_sum128(hi, lo);
+        if ((threadIdx.x & 63) == 0) {
+            s_hi[threadIdx.x >> 6] = hi;
+            s_lo[threadIdx.x >> 6] = lo;
+        }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         a.blocksum[(int64_t)b * a.nblk + blk] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        if (a.ess_frac > 0.0) {
+            unsigned long long hi = s_hi[0], lo = s_lo[0];
+            for (int w2 = 1; w2 < kBlock / 64; ++w2) add128(hi, lo, s_hi[w2], s_lo[w2]);
+            a.blocksum2[((int64_t)b * a.nblk + blk) * 2] = hi;
+            a.blocksum2[((int64_t)b * a.nblk + blk) * 2 + 1] = lo;
+        }
         if (blk == 0) {  // rand() of hmm_pf_resample.jl:27, once per segment instead of once per thread of k_offsets
             Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
             a.rsu[b] = u01(stream_next(rs));
@@ -803,15 +868,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
         bp[i] = run;
         run += bs[i];
     }
+    // ESS-adaptive mode: total of the squared weights and the decision (one thread; the tile count is small)
     if (threadIdx.x == kBlock - 1) {
         const unsigned long long W = run;
-        a.wtot[b] = W;
-        if (W == 0) {
-            a.ll[b] += -__builtin_inf();
-            atomicOr(&a.status[b], 2u /* DPOMP_ST_ZERO_WEIGHT */);
-        } else {
-            a.ll[b] += log_mean_weight(ordered_value(a.segmax[b]), W, a.sh, a.P);
+        bool resample = true;
+        if (a.ess_frac > 0.0) {
+            unsigned long long hi = 0, lo = 0;
+            const unsigned long long* b2 = a.blocksum2 + (int64_t)b * a.nblk * 2;
+            for (int i = 0; i < a.nblk; ++i) add128(hi, lo, b2[2 * i], b2[2 * i + 1]);
+            resample = ess_resample(W, hi, lo, a.ess_frac, a.P);
         }
+        finish_segment(a, b, W, resample);
     }
 }
 
@@ -827,22 +894,30 @@ template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     const int b = blockIdx.y, blk = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __shared__ unsigned long long s_w[kBlock / 64], s_pre[kBlock / 64], s_tot[kBlock / 64];
+    __shared__ unsigned long long s_w[kBlock / 64], s_pre[kBlock / 64], s_tot[kBlock / 64], s_hi[kBlock / 64],
+        s_lo[kBlock / 64];
     unsigned long long tile_prefix, W;
+    const bool adaptive = a.ess_frac > 0.0;
     if (FUSED) {
         const unsigned long long* bs = a.blocksum + (int64_t)b * a.nblk;
-        unsigned long long pre = 0, tot = 0;
+        unsigned long long pre = 0, tot = 0, hi = 0, lo = 0;
         for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
             const unsigned long long v = bs[i];
             tot += v;
             if (i < blk) pre += v;
+            if (adaptive) add128(hi, lo, a.blocksum2[((int64_t)b * a.nblk + i) * 2], a.blocksum2[((int64_t)b * a.nblk + i) * 2 + 1]);
         }
         pre = wave_sum(pre);
         tot = wave_sum(tot);
+        if (adaptive) wave_sum128(hi, lo);
         if (lane == 0) {
             s_pre[wid] = pre;
             s_tot[wid] = tot;
+            s_hi[wid] = hi;
+            s_lo[wid] = lo;
         }
+    } else if (adaptive && a.noresample[b]) {
+        return;  // k_scan_blocks decided to keep this segment's population
     }
     unsigned long long w[kItems];
     load_tile_weights(a, b, blk, w);
@@ -856,15 +931,14 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     if (FUSED) {
         tile_prefix = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
         W = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
-        if (blk == 0 && threadIdx.x == 0) {
-            a.wtot[b] = W;
-            if (W == 0) {
-                a.ll[b] += -__builtin_inf();
-                atomicOr(&a.status[b], 2u /* DPOMP_ST_ZERO_WEIGHT */);
-            } else {
-                a.ll[b] += log_mean_weight(ordered_value(a.segmax[b]), W, a.sh, a.P);
-            }
+        bool resample = true;
+        if (adaptive) {  // every workgroup reaches the same decision from the same exact sums
+            unsigned long long hi = s_hi[0], lo = s_lo[0];
+            for (int w2 = 1; w2 < kBlock / 64; ++w2) add128(hi, lo, s_hi[w2], s_lo[w2]);
+            resample = ess_resample(W, hi, lo, a.ess_frac, a.P);
         }
+        if (blk == 0 && threadIdx.x == 0) finish_segment(a, b, W, resample);
+        if (!resample) return;  // population kept: the gather copies it identically
     } else {
         tile_prefix = a.blockprefix[(int64_t)b * a.nblk + blk];
         W = a.wtot[b];
@@ -918,6 +992,7 @@ struct GatherArgs {
     int32_t* dst;
     const int32_t* offs;          // [B][Pp]  N_j
     const int32_t* first_parent;  // [B][nblk]
+    const int32_t* noresample;    // [B] or null: 1 = identity copy (ESS-adaptive mode kept the population)
     int64_t Pp;
     int32_t P, S, nblk;
 };
@@ -940,6 +1015,13 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
     const int64_t i0 = (int64_t)t_out * kTile + threadIdx.x * kItems;
     const int32_t* N = a.offs + (int64_t)b * a.Pp;
     const int32_t* fp = a.first_parent + (int64_t)b * a.nblk;
+    if (a.noresample && a.noresample[b]) {
+        for (int s = 0; s < a.S; ++s) {
+            const int64_t o = ((int64_t)b * a.S + s) * a.Pp + i0;
+            *reinterpret_cast<int4*>(a.dst + o) = *reinterpret_cast<const int4*>(a.src + o);
+        }
+        return;
+    }
     const int tlo = fp[t_out];
     const int thi = (t_out + 1 < a.nblk) ? fp[t_out + 1] : a.nblk - 1;  // ancestors are monotone in the slot index
     const int ntiles = thi - tlo + 1;
@@ -984,6 +1066,7 @@ struct GatherPosArgs {
     int32_t* dst;
     const double* posw;
     const double* tile_end_pos;
+    const int32_t* noresample;  // as in GatherArgs
     int64_t Pp;
     int32_t P, S, nblk, rs_type;
     uint32_t obs_k, seg_base;
@@ -1006,6 +1089,13 @@ __global__ __launch_bounds__(kBlock) void k_gather_pos(GatherPosArgs a) {
     const int64_t i0 = (int64_t)blockIdx.x * kTile + threadIdx.x * kItems;
     const double* pos = a.posw + (int64_t)b * a.Pp;
     const double* TE = a.tile_end_pos + (int64_t)b * a.nblk;
+    if (a.noresample && a.noresample[b]) {
+        for (int s = 0; s < a.S; ++s) {
+            const int64_t o = ((int64_t)b * a.S + s) * a.Pp + i0;
+            *reinterpret_cast<int4*>(a.dst + o) = *reinterpret_cast<const int4*>(a.src + o);
+        }
+        return;
+    }
     for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_tep[t] = TE[t];
     __syncthreads();
     int j[kItems];

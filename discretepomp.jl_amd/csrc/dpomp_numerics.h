@@ -228,6 +228,19 @@ DPOMP_D double log_mean_weight(double m, uint64_t W, int sh, int64_t P) {
     return m + dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
 }
 
+// ESS-adaptive mode: resample iff W^2 / sum w^2 < ess_frac * P, from the exact integer sums (sum w^2 as 128 bits).
+DPOMP_HD bool ess_resample(uint64_t W, uint64_t s2_hi, uint64_t s2_lo, double ess_frac, int64_t P) {
+    if (W == 0) return true;
+    const double Wd = u64_to_double(W);
+    const double s2 = u64_to_double(s2_hi) * 18446744073709551616.0 + u64_to_double(s2_lo);
+    return (Wd * Wd) / s2 < ess_frac * (double)P;
+}
+
+// log sum exp of the (possibly carried) log-weights: m + log(W 2^-sh).
+DPOMP_D double log_sum_weight(double m, uint64_t W, int sh) {
+    return m + dlog(u64_to_double(W) * (1.0 / (double)((uint64_t)1 << sh)));
+}
+
 // Order-preserving u64 key of a double, for integer atomicMax; key 0 sorts below every value.
 DPOMP_HD uint64_t ordered_key(double d) {
     const uint64_t b = double_to_bits(d);

@@ -20,4 +20,6 @@ int64_t hc_offspring_end(uint64_t c, uint64_t W, int64_t P, double r) { return d
 double hc_log_mean_weight(double m, uint64_t W, int sh, int64_t P) { return dpomp::log_mean_weight(m, W, sh, P); }
 double hc_ordered_roundtrip(double d) { return dpomp::ordered_value(dpomp::ordered_key(d)); }
 uint64_t hc_ordered_key(double d) { return dpomp::ordered_key(d); }
+int hc_ess_resample(uint64_t W, uint64_t hi, uint64_t lo, double frac, int64_t P) { return dpomp::ess_resample(W, hi, lo, frac, P) ? 1 : 0; }
+double hc_log_sum_weight(double m, uint64_t W, int sh) { return dpomp::log_sum_weight(m, W, sh); }
 }

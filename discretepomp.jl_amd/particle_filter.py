@@ -117,7 +117,7 @@ class ParticleFilter:
     """A model + data set bound to one GPU (``get_private_model``, src/DiscretePOMP.jl:96-99)."""
 
     def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], device: int = 0, rs_type: int = 1,
-                 essc: float = C_DF_ESS_CRIT, force_generic: bool = False):
+                 essc: float = C_DF_ESS_CRIT, force_generic: bool = False, ess_adaptive: bool = False):
         self._lib = _abi.load_library()
         self._h = C.c_void_p()
         self.device = int(device)
@@ -136,6 +136,8 @@ class ParticleFilter:
         self.rs_type = rs_type
         self._check(self._lib.dpomp_set_resampler(self._h, int(rs_type)))
         self.last_status: Optional[np.ndarray] = None
+        if ess_adaptive:  # opt-in: make `essc` do what its name says
+            self.set_ess_threshold(essc)
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc: int):
@@ -156,6 +158,10 @@ class ParticleFilter:
     def set_stream(self, raw_stream: Optional[int]):
         """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         self._check(self._lib.dpomp_set_stream(self._h, C.c_void_p(raw_stream or 0)))
+
+    def set_ess_threshold(self, ess_frac: float):
+        """ESS-adaptive resampling (0 = the reference's behaviour: resample at every weighted observation)."""
+        self._check(self._lib.dpomp_set_ess_threshold(self._h, float(ess_frac)))
 
     def set_propagate_variant(self, rpl: int):
         """Propagation-kernel variant (0 default, 1 static, 2/4 LDS queue, 16/32 compaction); never changes a result."""
@@ -274,7 +280,8 @@ def check_rate_source(model: DPOMPModel, obs_data: Sequence[Observation]) -> str
 
 
 def get_particle_filter_lpdf(model: DPOMPModel, obs_data: Sequence[Observation], np: int = C_DF_PF_P,
-                             rs_type: int = 1, essc: float = C_DF_ESS_CRIT, seed: int = 1, device: int = 0):
+                             rs_type: int = 1, essc: float = C_DF_ESS_CRIT, seed: int = 1, device: int = 0,
+                             ess_adaptive: bool = False):
     """Generate a SMC log-likelihood estimating function for ``model`` -- a.k.a. a particle filter
     (src/hmm_utils.jl:281-284, src/hmm_particle_filter.jl:87-101).
 
@@ -282,7 +289,7 @@ def get_particle_filter_lpdf(model: DPOMPModel, obs_data: Sequence[Observation],
     every call; here call ``n`` of the closure uses the stream ``(seed, n)``, or pass
     ``comp_log_pdf(parameters, seed=...)`` to pin it.
     """
-    pf = ParticleFilter(model, obs_data, device=device, rs_type=rs_type, essc=essc)
+    pf = ParticleFilter(model, obs_data, device=device, rs_type=rs_type, essc=essc, ess_adaptive=ess_adaptive)
     n_particles = int(np)
     state = {"calls": 0}
 

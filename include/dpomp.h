@@ -165,6 +165,13 @@ int dpomp_set_stream(dpomp_handle* h, void* hip_stream);
 /* rs_type as in get_particle_filter_lpdf (DPOMP_RS_*; default systematic). */
 int dpomp_set_resampler(dpomp_handle* h, int rs_type);
 
+/* ESS-adaptive resampling -- what the reference's dormant `essc` / `ess_rs_crit` argument describes
+ * (hmm_utils.jl:276-281) but never does: its test is commented out (hmm_particle_filter.jl:63-68) and it resamples at
+ * every weighted observation.  ess_frac = 0 (default) reproduces that.  ess_frac > 0: after weighting, resample only
+ * if ESS = (sum w)^2 / sum w^2 < ess_frac * P; otherwise keep the population and carry the log-weights into the next
+ * observation (increment = LSE(carried + new) - LSE(carried)).  The carry state lives in the population handle. */
+int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac);
+
 /* Tuning: variant of the propagation kernel.  0 = library default; 1 = one particle
  * per lane; 2, 4 = workgroup-local LDS queue with that many particles per lane and dynamic lane
  * refill; 16, 32 = one particle per lane with workgroup-level compaction every that many events.

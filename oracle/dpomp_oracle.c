@@ -363,13 +363,51 @@ typedef struct orc_trace {
     int32_t* particle_events; /* [T][P] executed events per particle and interval (work-balance analysis) */
 } orc_trace;
 
+/* Carried state of the ESS-adaptive mode between calls (the reference has no such state: its criterion is
+ * commented out, hmm_particle_filter.jl:63-68, and it resamples at every weighted observation). */
+typedef struct orc_carry {
+    int active;      /* weights were carried from the previous weighted observation */
+    double l_prev;   /* log sum exp of the carried log-weights */
+    double* a;       /* [P] carried log-weights */
+} orc_carry;
+
+static double u128_to_double(unsigned __int128 v) {
+    return u64_to_double((uint64_t)(v >> 64)) * 18446744073709551616.0 + u64_to_double((uint64_t)v);
+}
+
+/* SPEC resampling decision of the adaptive mode: ESS = W^2 / sum w^2 from the exact integer sums. */
+int orc_ess_resample(uint64_t W, uint64_t s2_hi, uint64_t s2_lo, double ess_frac, int64_t P) {
+    if (W == 0) return 1;
+    double Wd = u64_to_double(W);
+    double ess = (Wd * Wd) / u128_to_double(((unsigned __int128)s2_hi << 64) | s2_lo);
+    return ess < ess_frac * (double)P;
+}
+
+int orc_pf_partial_adaptive(const dpomp_model_desc* d, int64_t* pop, int64_t P, const double* theta,
+                            int ymin, int ymax, uint64_t seed, uint32_t seg, int mode, int rs_type,
+                            int nthreads, double ess_frac, orc_carry* carry, double* out_ll,
+                            uint32_t* out_status, uint64_t* out_events, const orc_trace* tr);
+
 int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const double* theta,
                    int ymin, int ymax, uint64_t seed, uint32_t seg, int mode, int rs_type,
                    int nthreads, double* out_ll, uint32_t* out_status, uint64_t* out_events,
                    const orc_trace* tr) {
+    return orc_pf_partial_adaptive(d, pop, P, theta, ymin, ymax, seed, seg, mode, rs_type, nthreads, 0.0, 0,
+                                   out_ll, out_status, out_events, tr);
+}
+
+/* ess_frac <= 0: the reference's behaviour (resample at every weighted observation but the last).
+ * ess_frac > 0 (SPEC mode only): resample only when ESS < ess_frac * P, otherwise carry the log-weights:
+ * t_p = a_p + g_p, log-likelihood increment = LSE(t) - LSE(a). */
+int orc_pf_partial_adaptive(const dpomp_model_desc* d, int64_t* pop, int64_t P, const double* theta,
+                            int ymin, int ymax, uint64_t seed, uint32_t seg, int mode, int rs_type,
+                            int nthreads, double ess_frac, orc_carry* carry, double* out_ll,
+                            uint32_t* out_status, uint64_t* out_events, const orc_trace* tr) {
     const int S = d->n_states, T = d->n_obs;
     if (ymin < 1 || ymax > T || ymin > ymax || P < 1) return DPOMP_EINVAL;
     if (rs_type < DPOMP_RS_SYSTEMATIC || rs_type > DPOMP_RS_MULTINOMIAL) return DPOMP_EINVAL;
+    if (ess_frac > 0.0 && (mode != ORC_MODE_SPEC || !carry || !carry->a)) return DPOMP_EINVAL;
+    if (ess_frac > 0.0 && ymin == 1) carry->active = 0;
     double t_prev;
     if (ymin == 1) { /* :41-45 */
         for (int64_t p = 0; p < P; ++p)
@@ -399,8 +437,9 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                     tr->states[((int64_t)k * tr->nkeep + p) * S + i] = pop[p + P * i];
         if (d->obs_id[k] > 0) { /* :58 */
             if (tr && tr->logw) memcpy(tr->logw, logw, sizeof(double) * P);
-            double inc;
+            double inc, lk = 0.0;
             uint64_t W = 0;
+            unsigned __int128 s2 = 0;
             if (mode == ORC_MODE_FAITHFUL) {
                 double total_weight = 0.0; /* :13 */
                 for (int64_t p = 0; p < P; ++p) {
@@ -409,12 +448,17 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                 }
                 inc = log(cw[P - 1] / (double)P); /* :60 */
             } else {
+                const int carried = ess_frac > 0.0 && carry->active;
+                if (carried)
+                    for (int64_t p = 0; p < P; ++p) logw[p] = logw[p] + carry->a[p]; /* t_p = g_p + a_p */
                 double m = -INFINITY;
                 for (int64_t p = 0; p < P; ++p)
                     if (logw[p] > m) m = logw[p];
                 uint64_t c = 0;
                 for (int64_t p = 0; p < P; ++p) {
-                    c += orc_fixed_weight(logw[p], m, sh);
+                    uint64_t wv = orc_fixed_weight(logw[p], m, sh);
+                    c += wv;
+                    s2 += (unsigned __int128)wv * wv;
                     cint[p] = c;
                 }
                 if (c == 0) {
@@ -422,13 +466,22 @@ int orc_pf_partial(const dpomp_model_desc* d, int64_t* pop, int64_t P, const dou
                 } else {
                     double Wd = u64_to_double(c);
                     W = c;
-                    inc = m + orc_dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
+                    lk = m + orc_dlog(Wd * (1.0 / (double)((uint64_t)1 << sh)));
+                    inc = carried ? lk - carry->l_prev
+                                  : m + orc_dlog((Wd * (1.0 / (double)((uint64_t)1 << sh))) / (double)P);
                 }
             }
             if (!(inc > -INFINITY)) status |= DPOMP_ST_ZERO_WEIGHT;
             output += inc; /* :60 */
             if (tr && tr->per_obs_ll) tr->per_obs_ll[k] = inc;
-            if (obs_i < T) { /* :62 */
+            if (obs_i < T && ess_frac > 0.0 &&
+                !orc_ess_resample(W, (uint64_t)(s2 >> 64), (uint64_t)s2, ess_frac, P)) {
+                /* ESS above the threshold: keep the population, carry the log-weights */
+                memcpy(carry->a, logw, sizeof(double) * P);
+                carry->active = 1;
+                carry->l_prev = lk;
+            } else if (obs_i < T) { /* :62 */
+                if (ess_frac > 0.0) carry->active = 0;
                 memcpy(old_p, pop, sizeof(int64_t) * P * S); /* old_p .= pop :66 */
                 uint64_t rs[2];
                 orc_stream_init(seed, seg, 0u, (uint32_t)k, ORC_DOMAIN_RESAMPLE, rs);

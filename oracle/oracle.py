@@ -60,6 +60,10 @@ def lib():
         L.orc_pf_partial.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, dp, C.c_int, C.c_int, C.c_uint64,
                                      C.c_uint32, C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_uint32),
                                      C.POINTER(C.c_uint64), C.POINTER(Trace)]
+        L.orc_pf_partial_adaptive.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, dp, C.c_int, C.c_int, C.c_uint64,
+                                              C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(Carry), dp,
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(Trace)]
+        L.orc_ess_resample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_int64]
         L.orc_pf_loglik.argtypes = [C.c_void_p, C.c_int64, dp, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, dp,
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(Trace)]
         L.orc_simulate_events.restype = C.c_int64
@@ -125,8 +129,20 @@ class PFResult:
     pass
 
 
+class Carry(C.Structure):
+    _fields_ = [("active", C.c_int), ("l_prev", C.c_double), ("a", C.POINTER(C.c_double))]
+
+
+class CarryState:
+    """Carried log-weights of the ESS-adaptive mode between incremental calls."""
+
+    def __init__(self, P):
+        self.a = np.zeros(P)
+        self.c = Carry(0, 0.0, _dp(self.a))
+
+
 def pf_partial(desc, pop, theta, ymin, ymax, seed=1, seg=0, mode=MODE_SPEC, rs_type=1, nthreads=1, trace=False,
-               nkeep=64):
+               nkeep=64, ess_frac=0.0, carry=None):
     """partial_log_likelihood! on a P x S int64 population (modified in place; pass a
     Fortran-ordered or (S,P)-transposed array: memory layout must be column-major P x S)."""
     P = pop.shape[0]
@@ -147,18 +163,22 @@ def pf_partial(desc, pop, theta, ymin, ymax, seed=1, seg=0, mode=MODE_SPEC, rs_t
         r.particle_events = np.zeros((T, P), dtype=np.int32)
         tr = Trace(_dp(r.per_obs_ll), _dp(r.logw), _ip(r.offspring_end), _ip(r.ancestors), _ip(r.states), min(nkeep, P),
                    r.particle_events.ctypes.data_as(C.POINTER(C.c_int32)))
-    rc = lib().orc_pf_partial(C.addressof(desc.c), _ip(flat), P, _dp(th), ymin, ymax, seed, seg, mode, rs_type, nthreads,
-                              C.byref(ll), C.byref(st), C.byref(ev), C.byref(tr) if tr is not None else None)
+    if ess_frac > 0.0 and carry is None:
+        carry = CarryState(P)
+    rc = lib().orc_pf_partial_adaptive(C.addressof(desc.c), _ip(flat), P, _dp(th), ymin, ymax, seed, seg, mode, rs_type,
+                                       nthreads, float(ess_frac), C.byref(carry.c) if carry is not None else None,
+                                       C.byref(ll), C.byref(st), C.byref(ev), C.byref(tr) if tr is not None else None)
     if rc != 0:
         raise RuntimeError(f"orc_pf_partial failed: {rc}")
     pop[:, :] = flat.T
     r.ll, r.status, r.events = ll.value, st.value, ev.value
+    r.carry = carry
     return r
 
 
-def pf_loglik(desc, P, theta, seed=1, seg=0, mode=MODE_SPEC, rs_type=1, nthreads=1, trace=False, nkeep=64):
+def pf_loglik(desc, P, theta, seed=1, seg=0, mode=MODE_SPEC, rs_type=1, nthreads=1, trace=False, nkeep=64, ess_frac=0.0):
     pop = np.zeros((P, desc.n_states), dtype=np.int64)
-    r = pf_partial(desc, pop, theta, 1, desc.n_obs, seed, seg, mode, rs_type, nthreads, trace, nkeep)
+    r = pf_partial(desc, pop, theta, 1, desc.n_obs, seed, seg, mode, rs_type, nthreads, trace, nkeep, ess_frac)
     r.pop = pop
     return r
 

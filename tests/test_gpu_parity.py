@@ -407,3 +407,40 @@ def test_three_million_particles_unfused_scan_path(dp, orc, make_obs, rs_type):
     assert np.array_equal(pop.download(0), ref.pop)
     assert pf.last_event_count() == ref.events
     pf.close()
+
+
+@pytest.mark.parametrize("rs_type", [1, 2, 3])
+@pytest.mark.parametrize("frac", [0.3, 0.6, 1.5])
+def test_ess_adaptive_resampling_matches_oracle(dp, orc, pooley, rs_type, frac):
+    """ESS-adaptive mode: segments of one batch take different resample/keep decisions, weights are carried on
+    the device; result and final populations equal the oracle's, for all three resamplers."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=rs_type, essc=frac, ess_adaptive=True)
+    P = 2500
+    theta = np.array([[0.003, 0.0028, 0.0034, 0.002], [0.1, 0.09, 0.12, 0.2]])
+    pop = pf.alloc_population(4, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=23, seg_base=1)
+    kept = 0
+    for b in range(4):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=23, seg=1 + b, rs_type=rs_type, ess_frac=frac)
+        plain = orc.pf_loglik(pf.desc, P, theta[:, b], seed=23, seg=1 + b, rs_type=rs_type)
+        assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
+        kept += ref.ll != plain.ll
+    if frac == 1.5:
+        assert kept == 0          # threshold above P: identical to the default path
+    if frac == 0.3:
+        assert kept >= 1          # at least one segment really skipped a resampling
+    pf.close()
+
+
+def test_ess_adaptive_state_survives_incremental_calls(dp, orc, pooley):
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, essc=0.3, ess_adaptive=True)
+    P, theta = 1800, [0.003, 0.1]
+    pop = pf.alloc_population(1, P)
+    parts = [pf.partial_log_likelihood(pop, theta, k, k, seed=31)[0] for k in range(1, pf.n_obs + 1)]
+    ref = orc.pf_loglik(pf.desc, P, theta, seed=31, ess_frac=0.3)
+    assert abs(sum(parts) - ref.ll) < 1e-12 and np.array_equal(pop.download(0), ref.pop)
+    full = pf.loglik(theta, P, seed=31)[0]
+    assert full == ref.ll
+    pf.set_ess_threshold(0.0)   # back to the reference's behaviour
+    assert pf.loglik(theta, P, seed=31)[0] == orc.pf_loglik(pf.desc, P, theta, seed=31).ll
+    pf.close()

@@ -75,3 +75,17 @@ def test_log_mean_weight_matches_direct_formula():
     for P, W, sh, m in [(1024, 300 << 52, 52, -2.1), (1 << 20, (1 << 57) + 12345, 42, -1.7)]:
         want = m + math.log(W / 2.0 ** sh / P)
         assert abs(L.hc_log_mean_weight(m, W, sh, P) - want) < 1e-13
+
+
+def test_ess_decision_bitwise(orc):
+    L, O = _hc(), orc.lib()
+    L.hc_ess_resample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_int64]
+    rng = np.random.default_rng(6)
+    for _ in range(3000):
+        P = int(rng.integers(1, 1 << 20))
+        w = rng.integers(0, 1 << 42, size=min(P, 64), dtype=np.uint64)
+        W = int(w.sum())
+        s2 = sum(int(x) * int(x) for x in w)
+        frac = float(rng.random())
+        assert L.hc_ess_resample(W, s2 >> 64, s2 & ((1 << 64) - 1), frac, P) == O.orc_ess_resample(W, s2 >> 64, s2 & ((1 << 64) - 1), frac, P)
+    assert L.hc_ess_resample(0, 0, 0, 0.5, 10) == 1

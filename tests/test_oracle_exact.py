@@ -111,3 +111,27 @@ def test_stratified_and_multinomial_resamplers(dp, orc, pooley, rs_type):
     lls = np.array([orc.pf_loglik(desc, 1024, theta, seed=200 + s, rs_type=rs_type).ll for s in range(120)])
     ratio = np.exp(lls - KNOWN[theta])
     assert abs(ratio.mean() - 1.0) < 3.5 * ratio.std(ddof=1) / math.sqrt(len(lls))
+
+
+def test_ess_adaptive_resampling_in_the_oracle(dp, orc, pooley):
+    """The dormant `essc` criterion made real (SPEC mode): a threshold above 1 resamples always and reproduces the
+    default path bit for bit; a real threshold changes the path, carries weights, and stays unbiased."""
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), pooley)
+    theta = (0.003, 0.1)
+    for seed in (1, 2, 3):
+        a = orc.pf_loglik(desc, 1024, theta, seed=seed, trace=True)
+        b = orc.pf_loglik(desc, 1024, theta, seed=seed, ess_frac=1.5, trace=True)
+        assert a.ll == b.ll and np.array_equal(a.pop, b.pop)
+    differs = sum(orc.pf_loglik(desc, 1024, theta, seed=s, ess_frac=0.3).ll != orc.pf_loglik(desc, 1024, theta, seed=s).ll for s in range(1, 11))
+    assert differs >= 5
+    lls = np.array([orc.pf_loglik(desc, 1024, theta, seed=300 + s, ess_frac=0.3).ll for s in range(140)])
+    ratio = np.exp(lls - KNOWN[theta])
+    assert abs(ratio.mean() - 1.0) < 3.5 * ratio.std(ddof=1) / math.sqrt(len(lls))
+    # incremental calls carry the state exactly like one call
+    pop = np.zeros((700, 2), dtype=np.int64)
+    carry, total = None, 0.0
+    for k in range(1, 6):
+        r = orc.pf_partial(desc, pop, theta, k, k, seed=9, ess_frac=0.3, carry=carry)
+        carry, total = r.carry, total + r.ll
+    full = orc.pf_loglik(desc, 700, theta, seed=9, ess_frac=0.3)
+    assert abs(total - full.ll) < 1e-12 and np.array_equal(pop, full.pop)
