@@ -125,6 +125,64 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
 end
 
 """
+    Filter(model, y, rate_source::String; n_params, obs_error=2.0, seq=(2,), device=0)
+
+A model whose rate function is arbitrary device code (compiled at run time with hipRTC): `rate_source` must define
+`__device__ void dpomp_user_rates(const double* theta, const int* x, double* r)`.  This is the route for a
+`DPOMPModel` whose `rate_function` closure is not one of the catalogue's (src/hmm_structs.jl:109).
+"""
+function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observation}, rate_source::String;
+                n_params::Integer, obs_error::Float64 = 2.0, seq = (2,), device::Integer = 0)
+    S, E = length(model.initial_condition), size(model.m_transition, 1)
+    V = length(y[1].val)
+    obs_time = Float64[o.time for o in y]
+    obs_id = Int64[o.obs_id for o in y]
+    obs_value = Int64[o.val[v] for o in y for v in 1:V]
+    pad(v, n, z) = ntuple(i -> i <= length(v) ? v[i] : z, n)
+    trans = zeros(Int32, MAX_EVENTS * MAX_STATES)
+    for e in 1:E, s in 1:S
+        trans[(e - 1) * MAX_STATES + s] = model.m_transition[e, s]
+    end
+    zero_term = RateTermC(0, 0, 0, (UInt32(0), UInt32(0)), UInt32(0))
+    desc = Ref(ModelDescC(1, S, E, n_params, 100 #= DPOMP_BUILTIN_USER =#, model.t0_index,
+                          pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
+                          ntuple(_ -> zero_term, MAX_EVENTS), ObsModelC(1, mask(seq), mask(seq), 0, obs_error),
+                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve obs_time obs_id obs_value begin
+        rc = ccall((:dpomp_create_with_source, LIB), Cint, (Ref{ModelDescC}, Cint, Cstring, Ref{Ptr{Cvoid}}),
+                   desc, device, rate_source, h)
+    end
+    rc == 0 || error("dpomp_create_with_source: ", unsafe_string(ccall((:dpomp_last_global_error, LIB), Cstring, ())))
+    f = Filter(h[], (obs_time, obs_id, obs_value), n_params, length(y))
+    finalizer(x -> ccall((:dpomp_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    return f
+end
+
+"Make `essc` do what its name says (the reference accepts and ignores it, src/hmm_particle_filter.jl:63-68); 0 = ignore."
+set_ess_threshold!(f::Filter, essc::Float64) =
+    check(f.handle, ccall((:dpomp_set_ess_threshold, LIB), Cint, (Ptr{Cvoid}, Cdouble), f.handle, essc))
+
+"""
+    simulate_events(f, theta; n_sims=1, seed=1, max_events=196000)
+
+`gillespie_sim` with the `Event` history (src/hmm_sim.jl:86-102) for `n_sims` trajectories at once: returns
+`(counts, times, types, states)`; `times[1:counts[i], i]`, `types[...]` (1-based event types) are trajectory i,
+`states[i, :, t]` its state at observation t.
+"""
+function simulate_events(f::Filter, theta::Vector{Float64}, S::Integer; n_sims::Integer = 1, seed::Integer = 1,
+                         max_events::Integer = 196000)
+    counts = Vector{Int64}(undef, n_sims)
+    times = Matrix{Float64}(undef, n_sims, max_events)      # event-major in memory: [p + n_sims*(n-1)]
+    types = Matrix{Int32}(undef, n_sims, max_events)
+    states = Array{Int64,3}(undef, n_sims, S, f.n_obs)
+    GC.@preserve theta counts times types states check(f.handle, ccall((:dpomp_simulate_events, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, UInt64, Int64, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int64}),
+        f.handle, theta, n_sims, seed, 0, max_events, counts, times, types, states))
+    return counts, permutedims(times), permutedims(types), states
+end
+
+"""
     get_particle_filter_lpdf(model, obs_data; np=200, rs_type=1, essc=0.3, seed=1) -> θ -> Float64
 
 Drop-in for `DiscretePOMP.get_particle_filter_lpdf` (src/hmm_utils.jl:281-284).
