@@ -115,3 +115,39 @@ def test_distributed_smc2_equals_single_process(tmp_path, dp, orc):
     for r in range(2):
         got = np.load(tmp_path / f"smc2_rank{r}.npz")
         assert np.array_equal(got["bme"], ref.bme) and np.array_equal(got["theta"], ref.theta) and np.array_equal(got["weight"], ref.weight)
+
+
+def _pmmh_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dpomp_amd as dp
+    from dpomp_amd import parallel
+    from oracle import oracle as orc
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), y)
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+
+    def evaluate(th, seed):  # chains sharded over ranks, log-likelihoods all-gathered
+        return parallel.sharded_loglik(
+            lambda t, base: np.array([orc.pf_loglik(desc, 64, t[:, j], seed=seed, seg=base + j).ll for j in range(t.shape[1])]), th)
+
+    init = np.array([[0.003, 0.0035, 0.0028], [0.1, 0.12, 0.09]])  # 3 chains on 2 ranks
+    out = dp.run_pmcmc(evaluate, prior, init, steps=60, adapt_period=30, seed=5, verbose=False)
+    np.save(os.path.join(out_dir, f"pmmh_rank{rank}.npy"), out.samples.theta)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_pmmh_equals_single_process(tmp_path, dp, orc):
+    mp.spawn(_pmmh_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), y)
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    init = np.array([[0.003, 0.0035, 0.0028], [0.1, 0.12, 0.09]])
+    ref = dp.run_pmcmc(lambda th, seed: np.array([orc.pf_loglik(desc, 64, th[:, c], seed=seed, seg=c).ll for c in range(th.shape[1])]),
+                       prior, init, steps=60, adapt_period=30, seed=5, verbose=False)
+    for r in range(2):
+        assert np.array_equal(np.load(tmp_path / f"pmmh_rank{r}.npy"), ref.samples.theta)
