@@ -283,7 +283,8 @@ class DPOMPModel:
 _T = lambda *a, **k: RateTerm(*a, **k)
 
 _CATALOGUE = {
-    # name: (dd terms, fd terms or None, builtin dd, builtin fd, transition, obs seq, stored name)
+    # name: (density-dependent terms, builtin id, builtin id of the frequency-dependent variant or None,
+    #        m_transition, observed state `seq`, model_name as stored by the reference)
     "SI": ([_T(1, ((1,), (2,)))], _abi.BUILTIN_SI, _abi.BUILTIN_SI_FD, [[-1, 1]], 2, "SI"),
     "SIR": ([_T(1, ((1,), (2,))), _T(2, ((2,),))], _abi.BUILTIN_SIR, _abi.BUILTIN_SIR_FD,
             [[-1, 1, 0], [0, -1, 1]], 2, "SIR"),

@@ -287,7 +287,9 @@ def get_particle_filter_lpdf(model: DPOMPModel, obs_data: Sequence[Observation],
 
     Returns ``comp_log_pdf(parameters) -> float``.  The reference advances Julia's global RNG on
     every call; here call ``n`` of the closure uses the stream ``(seed, n)``, or pass
-    ``comp_log_pdf(parameters, seed=...)`` to pin it.
+    ``comp_log_pdf(parameters, seed=...)`` to pin it.  ``rs_type``: 1 systematic (default), 2 stratified,
+    3 multinomial.  ``essc`` is accepted and ignored as in the reference unless ``ess_adaptive=True``, which turns
+    it into a real ESS threshold (resample only when ESS < essc * np).
     """
     pf = ParticleFilter(model, obs_data, device=device, rs_type=rs_type, essc=essc, ess_adaptive=ess_adaptive)
     n_particles = int(np)
