@@ -464,3 +464,31 @@ def test_unbiasedness_against_the_exact_likelihood_at_scale(dp, pooley, rs_type,
     assert se < 0.004
     assert abs((exact - lls.mean()) - lls.var() / 2) < 4 * lls.std() / math.sqrt(B) + 0.002
     pf.close()
+
+
+def test_t0_index_differs_per_segment(dp, orc, make_obs):
+    """Unknown initial time (DPOMPModel.t0_index): every segment of a batch starts its first interval at its own
+    theta[t0_index] (hmm_particle_filter.jl:45)."""
+    rf = dp.RateFunction([dp.RateTerm(1, ((1,), (2,))), dp.RateTerm(2, ((2,),))])
+    model = dp.generate_custom_model("SIS", rf, [100, 1], [[-1, 1], [1, -1]], t0_index=3, prior=dp.generate_weak_prior(3))
+    y = make_obs([20.0, 40.0, 60.0], [[0, 18], [0, 65], [0, 70]])
+    pf = dp.ParticleFilter(model, y)
+    theta = np.array([[0.003, 0.003, 0.0031], [0.1, 0.1, 0.11], [0.0, 7.5, 15.0]])
+    pop = pf.alloc_population(3, 1200)
+    ll = pf.partial_log_likelihood(pop, theta, 1, 3, seed=14)
+    for b in range(3):
+        ref = orc.pf_loglik(pf.desc, 1200, theta[:, b], seed=14, seg=b)
+        assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
+    assert ll[0] != ll[1]
+    pf.close()
+
+
+def test_batched_state_only_simulation(dp, orc):
+    model = dp.generate_model("LOTKA", [70, 70])
+    blank = dp.generate_observations(10.0, 5, 2)
+    pf = dp.ParticleFilter(model, blank)
+    theta = np.array([[0.5, 0.45], [0.0025, 0.003], [0.3, 0.35]])
+    got = pf.simulate(theta, n_sims=257, seed=8, seg_base=4)       # [B, T, S, n]
+    for b in range(2):
+        assert np.array_equal(got[b], orc.simulate(pf.desc, 257, theta[:, b], seed=8, seg=4 + b))
+    pf.close()
