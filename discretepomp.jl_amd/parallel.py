@@ -139,6 +139,8 @@ class ShardedBank(LocalBank):
         import torch
         import torch.distributed as dist
         mine = self.pop.export_state()
+        if dist.get_backend(self.group) != "nccl" and mine.is_cuda:
+            mine = mine.cpu()  # gloo group (tests, CPU-side rendezvous): stage the migration through the host
         pad = torch.zeros((self.width,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
         if not self.empty:
             pad[: self.hi - self.lo] = mine

@@ -95,7 +95,7 @@ class Population:
         return self.state_tensor(False)
 
     def import_state(self, t):
-        self.state_tensor(True).copy_(t)
+        self.state_tensor(True).copy_(t)  # accepts a host tensor too (copied H2D)
         import torch
         torch.cuda.current_stream(self._pf.device).synchronize()
 

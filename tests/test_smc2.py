@@ -136,3 +136,48 @@ def test_sharded_bank_on_gpu_matches_local_bank(dp, pooley):
         pf.close()
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_smc2_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dpomp_amd as dp
+    y = dp.get_observations(os.path.join(root, "tests", "golden", "pooley.csv"))
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    theta0 = prior.rand(np.random.default_rng(5), 101)
+    pf = dp.ParticleFilter(model, y, device=0)   # both ranks share the one GPU of the box
+    out = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 300, seed=9, rng=np.random.default_rng(11), verbose=False,
+                       distributed=True)
+    np.savez(os.path.join(out_dir, f"gpu_smc2_rank{rank}.npz"), bme=out.bme, theta=out.theta, weight=out.weight)
+    pf.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_process_sharded_smc2_on_gpu_filters(dp, pooley, tmp_path):
+    """Two ranks (gloo rendezvous), each running its block of theta-particles as device-resident filters on the GPU,
+    populations migrating between the processes at theta-level resampling: identical to the single-process run."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gpu_smc2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    model = dp.generate_model("SIS", [100, 1])
+    prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
+    theta0 = prior.rand(np.random.default_rng(5), 101)
+    pf = dp.ParticleFilter(model, pooley)
+    ref = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 300, seed=9, rng=np.random.default_rng(11), verbose=False)
+    pf.close()
+    assert ref.n_resample >= 1
+    for r in range(2):
+        got = np.load(tmp_path / f"gpu_smc2_rank{r}.npz")
+        assert np.array_equal(got["bme"], ref.bme) and np.array_equal(got["theta"], ref.theta) and np.array_equal(got["weight"], ref.weight)
