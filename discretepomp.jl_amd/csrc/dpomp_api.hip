@@ -25,9 +25,9 @@ namespace {
 
 thread_local std::string g_global_error;
 
-enum KernelId { KID_INIT = 0, KID_PROPAGATE, KID_WSUM, KID_SCAN_BLOCKS, KID_OFFSETS, KID_GATHER, KID_COPYSEG, KID_COUNT };
-const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum",         "k_scan_blocks",
-                                             "k_offsets", "k_gather",    "k_copy_segments"};
+enum KernelId { KID_INIT = 0, KID_PROPAGATE, KID_WSUM, KID_SCAN_BLOCKS, KID_OFFSETS, KID_GATHER, KID_COPYSEG, KID_FILTER_SMALL, KID_COUNT };
+const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum",          "k_scan_blocks",
+                                             "k_offsets", "k_gather",    "k_copy_segments", "k_filter_small"};
 
 typedef void (*PropFn)(PropArgs);
 
@@ -39,13 +39,15 @@ constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
 // particles per lane (chosen by how many particles the launch has, see pick_prop).
 typedef void (*SimFn)(SimArgs);
+typedef void (*SmallFn)(SmallArgs);
 struct PropSet {
     PropFn fn1, q2, q4, c16, c32;
     SimFn sim;
+    SmallFn small;
 };
 #define DPOMP_PROPSET(...)                                                                     \
     {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>, \
-     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>, k_simulate_rec<__VA_ARGS__>}
+     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>, k_simulate_rec<__VA_ARGS__>, k_filter_small<__VA_ARGS__>}
 
 struct PropEntry {
     int builtin, S, E;
@@ -79,7 +81,7 @@ PropSet generic_set(int S, int E) {
     DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
     DPOMP_G(8, 4) DPOMP_G(8, 8)
 #undef DPOMP_G
-    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 struct KernelStat {
@@ -103,12 +105,17 @@ struct dpomp_handle {
     std::vector<double> obs_time;
     std::vector<int64_t> obs_id;
     std::vector<long long> ysum;
-    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
     // run-time compiled rate evaluator (dpomp_create_with_source)
     bool rtc = false;
     hipModule_t rtc_module = nullptr;
-    hipFunction_t rtc_prop1 = nullptr, rtc_propc = nullptr, rtc_sim = nullptr;
+    hipFunction_t rtc_prop1 = nullptr, rtc_propc = nullptr, rtc_sim = nullptr, rtc_small = nullptr;
+    // observation data on the device (k_filter_small loops over the observations inside the kernel)
+    double* d_obs_time = nullptr;
+    long long* d_ysum = nullptr;
+    int32_t* d_obs_id = nullptr;
+    bool small_filter = true;  // whole-filter-per-workgroup kernel for P <= 256 (dpomp_set_propagate_variant(h, 1) etc. disable it)
     int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
                         // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
@@ -365,6 +372,51 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     HIPCHK(h, hipMemcpyAsync(p->theta, theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(p->ctl, 0, p->ctl_bytes, st));
 
+    // A filter that fits one workgroup runs whole in ONE kernel (all observations ymin..ymax, everything between
+    // the steps kept in LDS / registers) -- the regime of the reference's defaults (200 particles per filter).
+    if (p->P <= kBlock && h->small_filter && h->force_rpl == 0 && h->rs_type == DPOMP_RS_SYSTEMATIC && !adaptive &&
+        domain == DOMAIN_PROPAGATE && !record_states) {
+        SmallArgs sa;
+        sa.m = h->dm;
+        sa.state = p->state[p->cur];
+        sa.logw = p->logw;
+        sa.offs = p->offs;
+        sa.theta = p->theta;
+        sa.obs_time = h->d_obs_time;
+        sa.ysum = h->d_ysum;
+        sa.obs_id = h->d_obs_id;
+        sa.ll = p->ll;
+        sa.events = p->events;
+        sa.status = p->status;
+        sa.Pp = p->Pp;
+        sa.P = (int32_t)p->P;
+        sa.T = T;
+        sa.ymin = ymin;
+        sa.ymax = ymax;
+        sa.sh = weight_shift(p->P);
+        sa.seg_base = (uint32_t)seg_base;
+        sa.seed = seed;
+        {
+            ScopedTiming tm(h, KID_FILTER_SMALL);
+            if (h->rtc) {
+                void* params[] = {&sa};
+                HIPCHK(h, hipModuleLaunchKernel(h->rtc_small, (unsigned)B, 1, 1, kBlock, 1, 1, 0, st, params, nullptr));
+            } else {
+                hipLaunchKernelGGL(h->prop.small, dim3((unsigned)B), block, 0, st, sa);
+            }
+        }
+        p->initialised = true;
+        HIPCHK(h, hipGetLastError());
+        std::vector<char> result(p->ctl_result_bytes);
+        HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        collect_timings(h);
+        if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
+        memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
+        if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
+        return DPOMP_OK;
+    }
+
     if (ymin == 1) {  // pop[i,:] .= initial_condition  (:41-45)
         ScopedTiming tm(h, KID_INIT);
         hipLaunchKernelGGL(k_init, grid_tiles, block, 0, st, h->dm, p->state[p->cur], p->Pp);
@@ -545,11 +597,12 @@ RtcApi* rtc_api() {  // loaded on first use only: the library itself does not de
     return &api;
 }
 
-const char* const kRtcNames[3] = {"dpomp::k_propagate<dpomp::RUser>", "dpomp::k_propagate_c<dpomp::RUser, 32>",
-                                  "dpomp::k_simulate_rec<dpomp::RUser>"};
+constexpr int kRtcKernels = 4;
+const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>", "dpomp::k_propagate_c<dpomp::RUser, 32>",
+                                            "dpomp::k_simulate_rec<dpomp::RUser>", "dpomp::k_filter_small<dpomp::RUser>"};
 
 // Compiles kernels + user source.  On success `code` holds the gfx950 code object and `lowered` the mangled names.
-int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<char>& code, std::string lowered[3],
+int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<char>& code, std::string lowered[kRtcKernels],
                 std::string& log) {
     RtcApi* api = rtc_api();
     if (!api) {
@@ -584,7 +637,7 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
         if (log.empty()) log = "hiprtcCompileProgram failed";
         rc = DPOMP_EINVAL;
     } else {
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kRtcKernels; ++i) {
             const char* ln = nullptr;
             if (api->lowered(prog, kRtcNames[i], &ln) != HIPRTC_SUCCESS || !ln) rc = DPOMP_EDEVICE;
             else lowered[i] = ln;
@@ -648,7 +701,7 @@ int dpomp_check_rate_source(const dpomp_model_desc* d, const char* rate_source, 
     if (rc != DPOMP_OK) return rc;
     if (!rate_source) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
     std::vector<char> code;
-    std::string lowered[3], text;
+    std::string lowered[kRtcKernels], text;
     rc = rtc_compile(d, rate_source, code, lowered, text);
     if (log && log_size > 0) {
         strncpy(log, text.c_str(), (size_t)log_size - 1);
@@ -716,7 +769,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
     if (rate_source) {
         std::vector<char> code;
-        std::string lowered[3], text;
+        std::string lowered[kRtcKernels], text;
         rc = rtc_compile(d, rate_source, code, lowered, text);
         if (rc != DPOMP_OK) {
             rc = fail(nullptr, rc, "rate source does not compile: %.400s", text.c_str());
@@ -728,6 +781,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_prop1, h->rtc_module, lowered[0].c_str());
         if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_propc, h->rtc_module, lowered[1].c_str());
         if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_sim, h->rtc_module, lowered[2].c_str());
+        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_small, h->rtc_module, lowered[3].c_str());
         if (me != hipSuccess) {
             rc = fail(nullptr, DPOMP_EDEVICE, "loading the compiled rate module: %s", hipGetErrorString(me));
             (void)hipStreamDestroy(h->own_stream);
@@ -740,6 +794,21 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         h->prop_is_generic = true;
     }
     if (const char* env = getenv("DPOMP_RPL")) h->force_rpl = atoi(env);
+    {
+        std::vector<int32_t> oid(d->n_obs);
+        for (int t = 0; t < d->n_obs; ++t) oid[t] = d->obs_id[t] > 0 ? 1 : 0;
+        hipError_t oe = hipMalloc((void**)&h->d_obs_time, (size_t)d->n_obs * 8);
+        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_ysum, (size_t)d->n_obs * 8);
+        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_obs_id, (size_t)d->n_obs * 4);
+        if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_time, h->obs_time.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
+        if (oe == hipSuccess) oe = hipMemcpy(h->d_ysum, h->ysum.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
+        if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_id, oid.data(), (size_t)d->n_obs * 4, hipMemcpyHostToDevice);
+        if (oe != hipSuccess) {
+            rc = fail(nullptr, DPOMP_EDEVICE, "uploading the observation data: %s", hipGetErrorString(oe));
+            dpomp_destroy(h);
+            return rc;
+        }
+    }
     *out = h;
     return DPOMP_OK;
 }
@@ -752,6 +821,9 @@ void dpomp_destroy(dpomp_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->rtc_module) (void)hipModuleUnload(h->rtc_module);
+    (void)hipFree(h->d_obs_time);
+    (void)hipFree(h->d_ysum);
+    (void)hipFree(h->d_obs_id);
     if (h->scratch_pop) pop_release(h->scratch_pop);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

@@ -659,6 +659,174 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     }
 }
 
+// ---- k_filter_small: a whole filter per workgroup (P <= 256) ------------------------------------------------
+// The reference's default is 200 state particles per filter (C_DF_PF_P) under thousands of theta-particles
+// (SMC^2) or chains.  Such a filter fits one workgroup: one particle per lane, and everything the multi-kernel
+// path sends through HBM between launches stays on chip -- workgroup max and fixed-point sum (wave reductions +
+// LDS), inclusive scan of the weights, offspring boundaries N_j in LDS, ancestor search over them (8 LDS steps),
+// parents' states read from an LDS tile -- for ALL observations ymin..ymax in ONE launch (no kernel boundaries,
+// no global round trips, no wasted 1024-slot tiles).  Same numerical spec, same RNG keys: bit-identical to the
+// multi-kernel path and to the oracle.  Systematic resampling, non-adaptive mode.
+struct SmallArgs {
+    DevModel m;
+    int32_t* state;              // [B][S][Pp] current buffer (read when ymin > 1, written at the end)
+    double* logw;                // [B][Pp]  log-weights of the last weighted observation (inspection)
+    int32_t* offs;               // [B][Pp]  N_j of the last resampling (inspection)
+    const double* theta;         // [B][K]
+    const double* obs_time;      // [T]
+    const long long* ysum;       // [T]
+    const int32_t* obs_id;       // [T]
+    double* ll;                  // [B]
+    unsigned long long* events;  // [1]
+    uint32_t* status;            // [B]
+    int64_t Pp;
+    int32_t P, T, ymin, ymax, sh;
+    uint32_t seg_base;
+    uint64_t seed;
+};
+
+template <class R>
+__global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
+    constexpr int S = R::S, E = R::E;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
+    __shared__ double s_log[128][2];
+    __shared__ int32_t s_x[S][kBlock];
+    __shared__ int32_t s_N[kBlock];
+    __shared__ double s_wmax[kBlock / 64];
+    __shared__ unsigned long long s_wsum[kBlock / 64], s_ev[kBlock / 64];
+    __shared__ int s_cap[kBlock / 64];
+    __shared__ double s_r;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool valid = tid < a.P;
+    const int s_real = R::kGeneric ? a.m.S : S;
+    const int e_real = R::kGeneric ? a.m.E : E;
+    int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
+    const double* th = a.theta + (int64_t)b * a.m.K;
+    for (int i = tid; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+
+    int x[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        x[s] = (!valid || s >= s_real) ? 0 : (a.ymin == 1 ? a.m.x0[s] : st[(int64_t)s * a.Pp + tid]);
+    double t_prev = (a.ymin == 1) ? (a.m.t0_index > 0 ? th[a.m.t0_index - 1] : 0.0) : a.obs_time[a.ymin - 2];
+    const int cap = a.m.cap;
+    double ll = 0.0;
+    unsigned long long ev = 0;
+    bool any_cap = false, zero_w = false;
+    __syncthreads();
+
+    for (int obs_i = a.ymin; obs_i <= a.ymax; ++obs_i) {
+        const int k = obs_i - 1;
+        const double tmax = a.obs_time[k];
+        const bool weighted = a.obs_id[k] > 0;
+        // ---- iterate_particles!  (hmm_particle_filter.jl:9-33)
+        double time = t_prev;
+        Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)tid, (uint32_t)k, DOMAIN_PROPAGATE);
+        int n = 0;
+        bool capped = false;
+        if (valid) {
+            for (;;) {
+                double cum[E];
+                R::rates(a.m, th, x, cum);
+#pragma unroll
+                for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+                const double tot = cum[E - 1];
+                if (tot == 0.0) break;
+                time = time - dlog_tab(u01(stream_next(rng)), s_log) / tot;
+                if (time > tmax) break;
+                const double etc = u01(stream_next(rng)) * tot;
+                TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+                for (int i = E - 2; i >= 0; --i) {
+                    const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                    if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+                if (++n >= cap) {
+                    capped = true;
+                    break;
+                }
+            }
+        }
+        ev += (unsigned long long)n;
+        any_cap |= capped;
+        t_prev = tmax;  // :72
+        if (!weighted) continue;  // obs_id <= 0: propagate only (:58)
+
+        // ---- weights: log mean weight (:60) with the max factored out, fixed point
+        double g = -__builtin_inf();
+        if (valid) {
+            int xs = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (a.m.obs_state_mask & (1u << s)) xs += x[s];
+            const long long d = a.ysum[k] - (long long)xs;
+            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
+            a.logw[(int64_t)b * a.Pp + tid] = g;
+        }
+        const double wm = wave_max(g);
+        if (lane == 0) s_wmax[wid] = wm;
+#pragma unroll
+        for (int s = 0; s < S; ++s) s_x[s][tid] = x[s];  // parents' states for the gather below
+        __syncthreads();
+        const double m = fmax(fmax(s_wmax[0], s_wmax[1]), fmax(s_wmax[2], s_wmax[3]));
+        const unsigned long long w = valid ? fixed_weight(g, m, a.sh) : 0ull;
+        const unsigned long long incl = wave_inclusive_scan(w, lane);
+        if (lane == 63) s_wsum[wid] = incl;
+        if (tid == 0) {  // rand() of hmm_pf_resample.jl:27
+            Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, (uint32_t)k, DOMAIN_RESAMPLE);
+            s_r = u01(stream_next(rs));
+        }
+        __syncthreads();
+        unsigned long long c = incl;
+        for (int w2 = 0; w2 < wid; ++w2) c += s_wsum[w2];
+        const unsigned long long W = (s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]);
+        if (W == 0) {
+            ll += -__builtin_inf();
+            zero_w = true;
+        } else {
+            ll += log_mean_weight(m, W, a.sh, a.P);
+        }
+        if (obs_i < a.T) {  // :62 -- rsp_systematic (hmm_pf_resample.jl:24-42) through the offspring boundaries
+            const int nj = (W == 0) ? a.P : (int)offspring_end(c, W, a.P, s_r);
+            s_N[tid] = valid ? nj : a.P;
+            if (valid) a.offs[(int64_t)b * a.Pp + tid] = nj;
+            __syncthreads();
+            if (valid) {
+                int lo = 0, hi = a.P - 1;  // first j with N_j > tid
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_N[mid] > tid) hi = mid; else lo = mid + 1;
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] = s_x[s][lo];
+            }
+        }
+        __syncthreads();  // s_x / s_N / s_wmax are rewritten at the next observation
+    }
+
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+        if (valid && s < s_real) st[(int64_t)s * a.Pp + tid] = x[s];
+    const unsigned long long wev = wave_sum(ev);
+    const int wcap = __any(any_cap);
+    if (lane == 0) {
+        s_ev[wid] = wev;
+        s_cap[wid] = wcap;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.ll[b] += ll;
+        const unsigned long long be = (s_ev[0] + s_ev[1]) + (s_ev[2] + s_ev[3]);
+        if (be) atomicAdd(a.events, be);
+        const uint32_t stb = ((s_cap[0] | s_cap[1] | s_cap[2] | s_cap[3]) ? 1u : 0u) | (zero_w ? 2u : 0u);
+        if (stb) atomicOr(&a.status[b], stb);
+    }
+}
+
 // ---- k_simulate_rec: forward simulation with event recording -------------------------------------------
 // gillespie_sim (hmm_sim.jl:86-102): one trajectory per lane through all T observation intervals in one
 // launch (no resampling between them), every executed event appended as (time, 1-based type) to the

@@ -41,8 +41,8 @@ def test_device_numerics_match_oracle_bitwise(sis, orc):
     assert np.array_equal(ex, orc.dexp(-37.0 * x))
 
 
-@pytest.mark.parametrize("rpl", [1, 2, 4, 16, 32])
-@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097])
+@pytest.mark.parametrize("rpl", [0, 1, 2, 4, 16, 32])   # 0 = default: whole-filter kernel for P <= 256
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 200, 256, 257, 1000, 1024, 1025, 4097])
 def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
     """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane)."""
     theta = [0.003, 0.1]
@@ -131,7 +131,7 @@ def _synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99):
 
 
 @pytest.mark.parametrize("name,x0,fd,theta", CASES)
-@pytest.mark.parametrize("generic,rpl", [(False, 1), (True, 1), (False, 4), (True, 2), (False, 16), (True, 32)])
+@pytest.mark.parametrize("generic,rpl", [(False, 0), (True, 0), (False, 1), (True, 1), (False, 4), (True, 2), (False, 16), (True, 32)])
 def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rpl):
     """Every catalogue model, compiled built-in evaluator and table-driven generic evaluator,
     equals the oracle (which only knows the generic table)."""
@@ -139,7 +139,7 @@ def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rp
     y = _synthetic_data(dp, orc, model, theta)
     pf = dp.ParticleFilter(model, y, force_generic=generic)
     pf.set_propagate_variant(rpl)
-    P = 777
+    P = 200 if rpl == 0 else 777   # 200: the reference's default npf, served by the whole-filter kernel
     pop = pf.alloc_population(1, P)
     ll = pf.partial_log_likelihood(pop, theta, 1, len(y), seed=42)
     ref = orc.pf_loglik(pf.desc, P, theta, seed=42)
@@ -491,4 +491,28 @@ def test_batched_state_only_simulation(dp, orc):
     got = pf.simulate(theta, n_sims=257, seed=8, seg_base=4)       # [B, T, S, n]
     for b in range(2):
         assert np.array_equal(got[b], orc.simulate(pf.desc, 257, theta[:, b], seed=8, seg=4 + b))
+    pf.close()
+
+
+def test_small_filter_kernel_incremental_unweighted_and_batched(dp, orc, make_obs):
+    """The whole-filter-per-workgroup path (P <= 256): incremental calls resuming from stored populations, an
+    obs_id = 0 observation in the middle, t0_index, many segments; equal to the oracle and to the multi-kernel path."""
+    rf = dp.RateFunction([dp.RateTerm(1, ((1,), (2,))), dp.RateTerm(2, ((2,),))])
+    model = dp.generate_custom_model("SIS", rf, [100, 1], [[-1, 1], [1, -1]], t0_index=3, prior=dp.generate_weak_prior(3))
+    y = make_obs([20.0, 30.0, 40.0, 60.0, 80.0], [[0, 18], [0, 0], [0, 65], [0, 70], [0, 66]], obs_ids=[1, 0, 1, 1, 1])
+    pf = dp.ParticleFilter(model, y)
+    B, P = 37, 200
+    rng = np.random.default_rng(3)
+    theta = np.stack([rng.uniform(0.0025, 0.0035, B), rng.uniform(0.08, 0.12, B), rng.uniform(0.0, 10.0, B)])
+    pop = pf.alloc_population(B, P)
+    a = pf.partial_log_likelihood(pop, theta, 1, 2, seed=6, seg_base=2)
+    b = pf.partial_log_likelihood(pop, theta, 3, 5, seed=6, seg_base=2)
+    assert "k_filter_small" in pf.kernel_stats()
+    pf.set_propagate_variant(1)                       # the multi-kernel path on a second population
+    pop2 = pf.alloc_population(B, P)
+    full = pf.partial_log_likelihood(pop2, theta, 1, 5, seed=6, seg_base=2)
+    for s in rng.integers(0, B, 6):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, s], seed=6, seg=2 + int(s))
+        assert abs((a[s] + b[s]) - ref.ll) < 1e-12 and full[s] == ref.ll
+        assert np.array_equal(pop.download(int(s)), ref.pop) and np.array_equal(pop2.download(int(s)), ref.pop)
     pf.close()
