@@ -113,8 +113,12 @@ def test_sharded_bank_on_gpu_matches_local_bank(dp, pooley):
     device-resident populations and the RCCL all-gather of states used for theta-level migration."""
     import torch
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29617")
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+    sock.close()
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
