@@ -5,7 +5,7 @@ name; import it through the repo-root shim ``dpomp_amd`` (``import dpomp_amd``).
 """
 from ._abi import (DpompLibraryMissing, ST_EVENT_CAP, ST_ZERO_WEIGHT, RS_SYSTEMATIC, RS_STRATIFIED,
                    RS_MULTINOMIAL, DBG_LOGW, DBG_OFFSPRING_END, load_library)
-from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, RateFunction, RateSource, RateTerm,
+from .model import (DPOMPModel, GaussianObsModel, ModelDescriptor, Observation, RateFunction, RateSource, RateTerm, SourceObsModel,
                     UniformProductPrior, dmy_obs_fn, generate_custom_model, generate_model,
                     generate_weak_prior, get_observations, partial_gaussian_obs_model)
 from .smc2 import (ImportanceSample, compute_ess, compute_is_mu_covar, rs_systematic, run_ibis_analysis, run_pibis,

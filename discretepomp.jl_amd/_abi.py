@@ -23,6 +23,7 @@ ST_EVENT_CAP = 1
 ST_ZERO_WEIGHT = 2
 RATE_LEFT, RATE_RATIO = 0, 1
 OBS_GAUSSIAN = 1
+OBS_USER = 100
 RS_SYSTEMATIC, RS_STRATIFIED, RS_MULTINOMIAL = 1, 2, 3
 (BUILTIN_GENERIC, BUILTIN_SI, BUILTIN_SIR, BUILTIN_SEI, BUILTIN_SEIR, BUILTIN_SI_FD, BUILTIN_SIR_FD,
  BUILTIN_SEI_FD, BUILTIN_SEIR_FD, BUILTIN_LOTKA, BUILTIN_ROSSMAC) = range(11)

@@ -115,6 +115,9 @@ struct dpomp_handle {
     double* d_obs_time = nullptr;
     long long* d_ysum = nullptr;
     int32_t* d_obs_id = nullptr;
+    long long* d_obs_val = nullptr;  // [T][V] Observation.val (user observation models)
+    int n_obs_values = 0;
+    bool user_obs = false;
     bool small_filter = true;  // whole-filter-per-workgroup kernel for P <= 256 (dpomp_set_propagate_variant(h, 1) etc. disable it)
     int force_rpl = 0;  // propagate variant: 0 = auto; 1 = one particle per lane; 2, 4 = LDS queue with that
                         // many particles per lane; 16, 32 = compaction every that many events
@@ -237,8 +240,10 @@ int validate_desc(const dpomp_model_desc* d) {
     if (d->n_obs < 1 || !d->obs_time || !d->obs_id) return fail(nullptr, DPOMP_EINVAL, "no observations");
     if (d->n_obs_values < 0 || d->n_obs_values > 32 || (d->n_obs_values > 0 && !d->obs_value))
         return fail(nullptr, DPOMP_EINVAL, "n_obs_values %d invalid", d->n_obs_values);
-    if (d->obs.kind != DPOMP_OBS_GAUSSIAN) return fail(nullptr, DPOMP_EINVAL, "unknown observation model kind %d", d->obs.kind);
-    if (!(d->obs.sigma > 0.0)) return fail(nullptr, DPOMP_EINVAL, "obs.sigma must be positive");
+    if (d->obs.kind != DPOMP_OBS_GAUSSIAN && d->obs.kind != DPOMP_OBS_USER) return fail(nullptr, DPOMP_EINVAL, "unknown observation model kind %d", d->obs.kind);
+    if (d->obs.kind == DPOMP_OBS_USER && d->builtin_id != DPOMP_BUILTIN_USER)
+        return fail(nullptr, DPOMP_EINVAL, "a user observation model needs a run-time compiled model (DPOMP_BUILTIN_USER + dpomp_create_with_source)");
+    if (d->obs.kind == DPOMP_OBS_GAUSSIAN && !(d->obs.sigma > 0.0)) return fail(nullptr, DPOMP_EINVAL, "obs.sigma must be positive");
     if (d->obs.state_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "obs.state_mask names a state >= n_states");
     if (d->n_obs_values < 32 && (d->obs.value_mask >> d->n_obs_values)) return fail(nullptr, DPOMP_EINVAL, "obs.value_mask names a value column >= n_obs_values");
     for (int s = 0; s < d->n_states; ++s)
@@ -385,6 +390,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         sa.obs_time = h->d_obs_time;
         sa.ysum = h->d_ysum;
         sa.obs_id = h->d_obs_id;
+        sa.yval = h->d_obs_val;
+        sa.n_yval = h->n_obs_values;
         sa.ll = p->ll;
         sa.events = p->events;
         sa.status = p->status;
@@ -447,6 +454,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.use_theta_t0 = (obs_i == 1 && h->dm.t0_index > 0) ? 1 : 0;
         a.want_weight = weighted ? 1 : 0;
         a.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
+        a.yval = h->d_obs_val + (size_t)k * h->n_obs_values;
+        a.n_yval = h->n_obs_values;
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
             // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
@@ -611,11 +620,16 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
     }
     char head[512];
     snprintf(head, sizeof head, "#include \"dpomp_kernels.h\"\nnamespace dpomp {\n#line 1 \"rate_source\"\n");
-    char tail[1024];
+    const bool user_obs = d->obs.kind == DPOMP_OBS_USER;
+    char tail[1536];
     snprintf(tail, sizeof tail,
-             "\nstruct RUser : RBase<%d, %d> {\n  static __device__ __forceinline__ void rates(const DevModel&, const double* th, "
-             "const int (&x)[%d], double (&r)[%d]) { dpomp_user_rates(th, x, r); }\n};\n}  // namespace dpomp\n",
-             d->n_states, d->n_events, d->n_states, d->n_events);
+             "\nstruct RUser : RBase<%d, %d> {\n  static constexpr bool kUserObs = %s;\n"
+             "  static __device__ __forceinline__ void rates(const DevModel&, const double* th, "
+             "const int (&x)[%d], double (&r)[%d]) { dpomp_user_rates(th, x, r); }\n%s};\n}  // namespace dpomp\n",
+             d->n_states, d->n_events, user_obs ? "true" : "false", d->n_states, d->n_events,
+             user_obs ? "  static __device__ __forceinline__ double user_obs(const double* th, const int* x, const long long* y, int ny) "
+                        "{ return dpomp_user_obs(th, x, y, ny); }\n"
+                      : "");
     const std::string src = std::string(head) + rate_source + tail;
     const char* headers[3] = {kSrcKernels, kSrcNumerics, kSrcLogTable};
     const char* names[3] = {"dpomp_kernels.h", "dpomp_numerics.h", "dpomp_log_table.h"};
@@ -754,8 +768,9 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     int64_t cap = d->max_events_per_interval > 0 ? d->max_events_per_interval : ((int64_t)1 << 22);
     if (cap > 0x7FFFFFFF) cap = 0x7FFFFFFF;
     m.cap = (int32_t)cap;
-    m.obs_tmp1 = std::log(1.0 / (std::sqrt(2.0 * M_PI) * d->obs.sigma));  // hmm_examples.jl:61
-    m.obs_tmp2 = 2.0 * d->obs.sigma * d->obs.sigma;                        // :62
+    const double sigma = d->obs.kind == DPOMP_OBS_GAUSSIAN ? d->obs.sigma : 1.0;
+    m.obs_tmp1 = std::log(1.0 / (std::sqrt(2.0 * M_PI) * sigma));  // hmm_examples.jl:61
+    m.obs_tmp2 = 2.0 * sigma * sigma;                              // :62
     for (int ev = 0; ev < 8; ++ev) {
         uint64_t w = 0;
         if (ev < d->n_events)
@@ -803,6 +818,12 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_time, h->obs_time.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_ysum, h->ysum.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_id, oid.data(), (size_t)d->n_obs * 4, hipMemcpyHostToDevice);
+        h->n_obs_values = d->n_obs_values;
+        const size_t nval = (size_t)d->n_obs * (d->n_obs_values > 0 ? d->n_obs_values : 1);
+        std::vector<long long> vals(nval, 0);
+        for (size_t i = 0; i < (size_t)d->n_obs * d->n_obs_values; ++i) vals[i] = d->obs_value[i];
+        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_obs_val, nval * 8);
+        if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_val, vals.data(), nval * 8, hipMemcpyHostToDevice);
         if (oe != hipSuccess) {
             rc = fail(nullptr, DPOMP_EDEVICE, "uploading the observation data: %s", hipGetErrorString(oe));
             dpomp_destroy(h);
@@ -824,6 +845,7 @@ void dpomp_destroy(dpomp_handle* h) {
     (void)hipFree(h->d_obs_time);
     (void)hipFree(h->d_ysum);
     (void)hipFree(h->d_obs_id);
+    (void)hipFree(h->d_obs_val);
     if (h->scratch_pop) pop_release(h->scratch_pop);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

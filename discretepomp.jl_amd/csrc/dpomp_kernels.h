@@ -67,6 +67,8 @@ struct PropArgs {
     int32_t use_theta_t0;  // first interval of a ymin == 1 call with t0_index > 0
     int32_t want_weight;
     const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
+    const long long* yval;    // [V] Observation.val of this observation (user observation models)
+    int32_t n_yval;
 };
 
 // ---- rate evaluators (the pluggable part) -------------------------------------------------
@@ -76,6 +78,7 @@ template <int S_, int E_>
 struct RGeneric {  // interprets DevModel::rate (any model that fits the descriptor)
     static constexpr int S = S_, E = E_;
     static constexpr bool kGeneric = true;
+    static constexpr bool kUserObs = false;
     static __device__ __forceinline__ int msum(uint32_t mask, const int (&x)[S]) {
         int s = 0;
 #pragma unroll
@@ -115,6 +118,7 @@ template <int S_, int E_>
 struct RBase {
     static constexpr int S = S_, E = E_;
     static constexpr bool kGeneric = false;
+    static constexpr bool kUserObs = false;
     static __device__ __forceinline__ double total(const int (&x)[S_]) {
         int s = 0;
 #pragma unroll
@@ -183,6 +187,24 @@ struct RRossmac : RBase<4, 6> {
         r[5] = th[3] * (double)x[1];
     }
 };
+
+// Observation log-density of one particle: partial_gaussian_obs_model (hmm_examples.jl:59-67),
+//   tmp1 - (sum(y.val[y_seq]) - sum(pop[seq]))^2 / tmp2   with the integer square taken before the promotion,
+// or, for run-time compiled models that define it, the user's dpomp_user_obs(theta, x, y.val, length(y.val)).
+template <class R>
+__device__ __forceinline__ double obs_log_weight(const DevModel& m, const double* th, const int (&x)[R::S], long long ysum,
+                                                 const long long* yval, int n_yval) {
+    if constexpr (R::kUserObs) {
+        return R::user_obs(th, x, yval, n_yval);
+    } else {
+        int xs = 0;
+#pragma unroll
+        for (int s = 0; s < R::S; ++s)
+            if (m.obs_state_mask & (1u << s)) xs += x[s];
+        const long long d = ysum - (long long)xs;
+        return m.obs_tmp1 - ((double)(d * d)) / m.obs_tmp2;
+    }
+}
 
 // ---- wave / block helpers --------------------------------------------------------------
 __device__ __forceinline__ double wave_max(double v) {
@@ -281,12 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
         for (int s = 0; s < S; ++s)
             if (s < s_real) st[(int64_t)s * a.Pp + p] = x[s];
         if (a.want_weight) {
-            int xs = 0;
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (a.m.obs_state_mask & (1u << s)) xs += x[s];
-            const long long d = a.ysum - (long long)xs;
-            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            g = obs_log_weight<R>(a.m, th, x, a.ysum, a.yval, a.n_yval);
             if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
             if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
             a.logw[(int64_t)b * a.Pp + p] = g;
@@ -439,20 +456,18 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         const int idx = jj * kBlock + threadIdx.x;
         if (idx < cnt) {
             const int p = base + idx;
-            int xs = 0;
+            int xv[S];
 #pragma unroll
             for (int s = 0; s < S; ++s) {
-                const int v = s_x[s][idx];
-                if (s < s_real) st[(int64_t)s * a.Pp + p] = v;
-                if (a.m.obs_state_mask & (1u << s)) xs += v;
+                xv[s] = s_x[s][idx];
+                if (s < s_real) st[(int64_t)s * a.Pp + p] = xv[s];
             }
             const int c = s_cnt[idx];
             ev += (unsigned long long)(c & 0x7FFFFFFF);
             const bool capped = c < 0;
             any_cap |= capped;
             if (a.want_weight) {
-                const long long d = a.ysum - (long long)xs;
-                double g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+                double g = obs_log_weight<R>(a.m, th, xv, a.ysum, a.yval, a.n_yval);
                 if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
                 if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
                 a.logw[(int64_t)b * a.Pp + p] = g;
@@ -616,19 +631,17 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     unsigned long long ev = 0;
     capped = false;
     if (valid) {
-        int xs = 0;
+        int xv[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int v = s_res[s][threadIdx.x];
-            if (s < s_real) st[(int64_t)s * a.Pp + p] = v;
-            if (a.m.obs_state_mask & (1u << s)) xs += v;
+            xv[s] = s_res[s][threadIdx.x];
+            if (s < s_real) st[(int64_t)s * a.Pp + p] = xv[s];
         }
         const int c = s_cnt[threadIdx.x];
         ev = (unsigned long long)(c & 0x7FFFFFFF);
         capped = c < 0;
         if (a.want_weight) {
-            const long long d = a.ysum - (long long)xs;
-            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            g = obs_log_weight<R>(a.m, th, xv, a.ysum, a.yval, a.n_yval);
             if (a.carry_in && a.carry_in[b]) g = g + a.logw[(int64_t)b * a.Pp + p];  // t_p = g_p + a_p
             if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
             a.logw[(int64_t)b * a.Pp + p] = g;
@@ -676,6 +689,8 @@ struct SmallArgs {
     const double* obs_time;      // [T]
     const long long* ysum;       // [T]
     const int32_t* obs_id;       // [T]
+    const long long* yval;       // [T][V] Observation.val (user observation models)
+    int32_t n_yval;
     double* ll;                  // [B]
     unsigned long long* events;  // [1]
     uint32_t* status;            // [B]
@@ -758,12 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         // ---- weights: log mean weight (:60) with the max factored out, fixed point
         double g = -__builtin_inf();
         if (valid) {
-            int xs = 0;
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (a.m.obs_state_mask & (1u << s)) xs += x[s];
-            const long long d = a.ysum[k] - (long long)xs;
-            g = a.m.obs_tmp1 - ((double)(d * d)) / a.m.obs_tmp2;
+            g = obs_log_weight<R>(a.m, th, x, a.ysum[k], a.yval + (int64_t)k * a.n_yval, a.n_yval);
             if (capped || !(g > -__builtin_inf())) g = -__builtin_inf();
             a.logw[(int64_t)b * a.Pp + tid] = g;
         }

@@ -112,7 +112,7 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
     desc = Ref(ModelDescC(1, S, E, K, freq_dep ? b_fd : b_dd, model.t0_index,
                           pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
                           pad(terms, MAX_EVENTS, zero_term),
-                          ObsModelC(1, mask(seq), mask(seq), 0, obs_error),
+                          ObsModelC(user_obs ? 100 : 1, mask(seq), mask(seq), 0, obs_error),
                           length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve obs_time obs_id obs_value begin
@@ -125,14 +125,17 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
 end
 
 """
-    Filter(model, y, rate_source::String; n_params, obs_error=2.0, seq=(2,), device=0)
+    Filter(model, y, rate_source::String; n_params, obs_error=2.0, seq=(2,), user_obs=false, device=0)
 
 A model whose rate function is arbitrary device code (compiled at run time with hipRTC): `rate_source` must define
 `__device__ void dpomp_user_rates(const double* theta, const int* x, double* r)`.  This is the route for a
-`DPOMPModel` whose `rate_function` closure is not one of the catalogue's (src/hmm_structs.jl:109).
+`DPOMPModel` whose `rate_function` closure is not one of the catalogue's (src/hmm_structs.jl:109).  With
+`user_obs=true` the source also defines `__device__ double dpomp_user_obs(const double* theta, const int* x,
+const long long* y, int n_y)` (log density), replacing the Gaussian observation model (src/hmm_structs.jl:113).
 """
 function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observation}, rate_source::String;
-                n_params::Integer, obs_error::Float64 = 2.0, seq = (2,), device::Integer = 0)
+                n_params::Integer, obs_error::Float64 = 2.0, seq = (2,), user_obs::Bool = false,
+                device::Integer = 0)
     S, E = length(model.initial_condition), size(model.m_transition, 1)
     V = length(y[1].val)
     obs_time = Float64[o.time for o in y]
@@ -146,7 +149,7 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
     zero_term = RateTermC(0, 0, 0, (UInt32(0), UInt32(0)), UInt32(0))
     desc = Ref(ModelDescC(1, S, E, n_params, 100 #= DPOMP_BUILTIN_USER =#, model.t0_index,
                           pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
-                          ntuple(_ -> zero_term, MAX_EVENTS), ObsModelC(1, mask(seq), mask(seq), 0, obs_error),
+                          ntuple(_ -> zero_term, MAX_EVENTS), ObsModelC(user_obs ? 100 : 1, mask(seq), mask(seq), 0, obs_error),
                           length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve obs_time obs_id obs_value begin

@@ -212,6 +212,21 @@ class GaussianObsModel:
         return self.tmp1 - float(d * d) / self.tmp2
 
 
+class SourceObsModel:
+    """An observation model given as device code: the rate source of the model (:class:`RateSource`) must then also
+    define ``__device__ double dpomp_user_obs(const double* theta, const int* x, const long long* y, int n_y)``
+    returning ``log p(y | x, theta)`` -- the counterpart of the reference's arbitrary ``obs_model(y, population,
+    theta)`` closure (hmm_structs.jl:113).  ``host`` is an optional Python callable with that signature."""
+
+    def __init__(self, host: Optional[Callable] = None):
+        self.host = host
+
+    def __call__(self, y: Observation, population, theta=None) -> float:
+        if self.host is None:
+            raise NotImplementedError("this SourceObsModel has no host implementation (pass host=...)")
+        return self.host(y, population, theta)
+
+
 def partial_gaussian_obs_model(sigma: float = 2.0, seq=(2,), y_seq=None) -> GaussianObsModel:
     return GaussianObsModel(sigma, seq, y_seq)
 
@@ -363,8 +378,11 @@ class ModelDescriptor:
             raise ValueError("m_transition must be n_events x n_states")
         if model.rate_function.n_events != E:
             raise ValueError("rate_function and m_transition disagree on the number of events")
-        if not isinstance(model.obs_model, GaussianObsModel):
-            raise TypeError("obs_model must come from partial_gaussian_obs_model (the device evaluates it)")
+        user_obs = isinstance(model.obs_model, SourceObsModel)
+        if user_obs and not isinstance(model.rate_function, RateSource):
+            raise TypeError("a SourceObsModel needs a RateSource whose text defines dpomp_user_obs")
+        if not user_obs and not isinstance(model.obs_model, GaussianObsModel):
+            raise TypeError("obs_model must come from partial_gaussian_obs_model or be a SourceObsModel (the device evaluates it)")
         if len(obs_data) < 1:
             raise ValueError("no observations")
         K = model.n_params
@@ -396,12 +414,16 @@ class ModelDescriptor:
         if any(len(o.val) != V for o in obs_data):
             raise ValueError("every Observation.val must have the same length")
         om = model.obs_model
-        d.obs.kind = _abi.OBS_GAUSSIAN
-        d.obs.state_mask = _mask(om.seq)
-        d.obs.value_mask = _mask(om.y_seq)
-        d.obs.sigma = om.sigma
-        if max(om.seq) > S or max(om.y_seq) > V:
-            raise IndexError("observation model indexes beyond the state / observation vector")
+        if user_obs:
+            d.obs.kind = _abi.OBS_USER
+            d.obs.sigma = 1.0
+        else:
+            d.obs.kind = _abi.OBS_GAUSSIAN
+            d.obs.state_mask = _mask(om.seq)
+            d.obs.value_mask = _mask(om.y_seq)
+            d.obs.sigma = om.sigma
+            if max(om.seq) > S or max(om.y_seq) > V:
+                raise IndexError("observation model indexes beyond the state / observation vector")
         self.obs_time = np.ascontiguousarray([o.time for o in obs_data], dtype=np.float64)
         self.obs_id = np.ascontiguousarray([o.obs_id for o in obs_data], dtype=np.int64)
         self.obs_value = np.ascontiguousarray([[int(v) for v in o.val] for o in obs_data], dtype=np.int64).reshape(-1)

@@ -77,6 +77,7 @@ extern "C" {
 
 /* observation models */
 #define DPOMP_OBS_GAUSSIAN 1 /* partial_gaussian_obs_model hmm_examples.jl:59-67 */
+#define DPOMP_OBS_USER 100   /* log-density from run-time compiled source: dpomp_user_obs (dpomp_create_with_source) */
 
 /* resamplers (rs_type of get_particle_filter_lpdf, hmm_utils.jl:281) */
 #define DPOMP_RS_SYSTEMATIC 1 /* rsp_systematic hmm_pf_resample.jl:24-42 (the reference's only working one) */
@@ -151,7 +152,11 @@ int dpomp_create(const dpomp_model_desc* desc, int device, dpomp_handle** out);
 /* A model whose rate function is arbitrary device code -- the closest thing to the reference's
  * `rate_function::Function` closure (hmm_structs.jl:109).  `rate_source` is HIP C++ that defines
  *     __device__ void dpomp_user_rates(const double* theta, const int* x, double* r);
- * writing the E (un-cumulated) event rates for parameter vector theta[K] and state x[S].  It is compiled with
+ * writing the E (un-cumulated) event rates for parameter vector theta[K] and state x[S].  If desc->obs.kind is
+ * DPOMP_OBS_USER the text must also define the observation model (the reference's `obs_model(y, pop, theta)` closure,
+ * hmm_structs.jl:113):
+ *     __device__ double dpomp_user_obs(const double* theta, const int* x, const long long* y, int n_y);
+ * returning log p(y | x, theta) for Observation.val = y[0..n_y).  It is compiled with
  * hipRTC for gfx950 together with the library's kernels (-ffp-contract=off: results stay reproducible by the
  * same source compiled for the host).  desc->builtin_id must be DPOMP_BUILTIN_USER. */
 int dpomp_create_with_source(const dpomp_model_desc* desc, int device, const char* rate_source, dpomp_handle** out);

@@ -238,7 +238,25 @@ static int64_t obs_value_sum(const dpomp_model_desc* d, int k) {
 /* partial_gaussian_obs_model, hmm_examples.jl:59-67:
  *   tmp1 = log(1/(sqrt(2 pi) sigma)); tmp2 = 2 sigma^2;
  *   tmp1 - ((sum(y.val[y_seq]) - sum(pop[seq]))^2) / tmp2      (integer square, then Float64) */
+typedef double (*orc_user_obs_fn)(const double* theta, const int* x, const long long* y, int ny);
+static orc_user_obs_fn g_user_obs = 0;
+static const double* g_obs_theta = 0; /* set per call by the filter (the obs model receives theta) */
+void orc_set_user_obs(orc_user_obs_fn fn) { g_user_obs = fn; }
+
+double orc_obs_loglik_theta(const dpomp_model_desc* d, int k, const int64_t* x, const double* theta);
+
 double orc_obs_loglik(const dpomp_model_desc* d, int k, const int64_t* x) {
+    return orc_obs_loglik_theta(d, k, x, g_obs_theta);
+}
+
+double orc_obs_loglik_theta(const dpomp_model_desc* d, int k, const int64_t* x, const double* theta) {
+    if (d->obs.kind == DPOMP_OBS_USER && g_user_obs) { /* host twin of dpomp_user_obs (obs_model(y, pop, theta)) */
+        int xi[DPOMP_MAX_STATES];
+        long long yv[32];
+        for (int i = 0; i < d->n_states; ++i) xi[i] = (int)x[i];
+        for (int v = 0; v < d->n_obs_values; ++v) yv[v] = d->obs_value[(int64_t)k * d->n_obs_values + v];
+        return g_user_obs(theta, xi, yv, d->n_obs_values);
+    }
     double sigma = d->obs.sigma;
     double tmp1 = log(1.0 / (sqrt(2.0 * M_PI) * sigma));
     double tmp2 = 2.0 * sigma * sigma;
@@ -299,7 +317,7 @@ void orc_iterate_particles(const dpomp_model_desc* d, int64_t* pop, int64_t P, c
         uint64_t s[2];
         orc_stream_init(seed, seg, (uint32_t)p, (uint32_t)k, ORC_DOMAIN_PROPAGATE, s);
         int64_t n = gillespie_advance(d, theta, x, t, tmax, s, mode, cap);
-        double g = orc_obs_loglik(d, k, x); /* :29 */
+        double g = orc_obs_loglik_theta(d, k, x, theta); /* :29 */
         if (n < 0) {
             st |= DPOMP_ST_EVENT_CAP;
             g = -INFINITY;

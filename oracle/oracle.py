@@ -70,6 +70,7 @@ def lib():
         L.orc_simulate_events.argtypes = [C.c_void_p, dp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, dp,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         L.orc_set_user_rates.argtypes = [C.c_void_p]
+        L.orc_set_user_obs.argtypes = [C.c_void_p]
         L.orc_simulate.argtypes = [C.c_void_p, C.c_int64, dp, C.c_uint64, C.c_uint32, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
@@ -209,14 +210,18 @@ def set_user_rates_from_source(source: str, workdir: str):
     oracle's rate function for DPOMP_BUILTIN_USER models."""
     src = os.path.join(workdir, "user_rates.cpp")
     so = os.path.join(workdir, f"libuser_rates_{len(_user_libs)}.so")
+    has_obs = "dpomp_user_obs" in source
     with open(src, "w") as f:
         f.write('#include <cmath>\n#define __device__\n#define __forceinline__ inline\n' + source +
-                '\nextern "C" void orc_user_rates_entry(const double* th, const int* x, double* r) { dpomp_user_rates(th, x, r); }\n')
+                '\nextern "C" void orc_user_rates_entry(const double* th, const int* x, double* r) { dpomp_user_rates(th, x, r); }\n' +
+                ('extern "C" double orc_user_obs_entry(const double* th, const int* x, const long long* y, int ny) '
+                 '{ return dpomp_user_obs(th, x, y, ny); }\n' if has_obs else ''))
     fma = ["-mfma"] if " fma" in open("/proc/cpuinfo").read() else []
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", *fma, "-fPIC", "-shared", "-o", so, src])
     ul = C.CDLL(so)
     _user_libs.append(ul)
     lib().orc_set_user_rates(C.cast(ul.orc_user_rates_entry, C.c_void_p))
+    lib().orc_set_user_obs(C.cast(ul.orc_user_obs_entry, C.c_void_p) if has_obs else None)
 
 
 def max_threads():

@@ -76,3 +76,55 @@ def test_rate_source_simulation_matches_oracle(dp, orc, tmp_path):
     for i, r in enumerate(res):
         n, times, types, states = orc.simulate_events(desc, [0.003, 0.1, 0.01, 0.02], seed=5, p=i)
         assert [e.time for e in r.particle.trajectory] == list(times) and r.particle.final_condition == list(states[-1])
+
+
+# ---- user observation models ------------------------------------------------------------------------------
+# Laplace (double-exponential) observation error with a reporting fraction: log p = -|y - rho*I| / b - log(2 b),
+# written with IEEE-exact operations only (theta[3] carries log(2b)), so host and device agree to the bit.
+SOURCE_OBS = SOURCE + """
+__device__ double dpomp_user_obs(const double* theta, const int* x, const long long* y, int n_y) {
+    const double mean = 0.9 * (double)x[1];
+    double d = (double)y[n_y - 1] - mean;
+    if (d < 0.0) d = -d;
+    return -d / 3.0 - 1.791759469228055;   // b = 3, log(6)
+}
+"""
+
+
+def _obs_host(y, pop, theta):
+    return -abs(y.val[-1] - 0.9 * pop[1]) / 3.0 - 1.791759469228055
+
+
+def _model_obs(dp):
+    rf = dp.RateSource(SOURCE_OBS, n_events=2, n_params=4, host=_host)
+    return dp.generate_custom_model("SIS-laplace", rf, [100, 1], [[-1, 1], [1, -1]], obs_model=dp.SourceObsModel(_obs_host),
+                                    prior=dp.generate_weak_prior(4))
+
+
+def test_user_obs_model_compiles_and_runs_in_the_oracle(dp, orc, pooley, tmp_path):
+    model = _model_obs(dp)
+    assert "error" not in dp.check_rate_source(model, pooley).lower()
+    desc = dp.ModelDescriptor(model, pooley)
+    assert desc.c.obs.kind == 100
+    orc.set_user_rates_from_source(SOURCE_OBS, str(tmp_path))
+    for I in (0, 17, 65):
+        assert orc.obs_loglik(desc, 1, [101 - I, I]) == _obs_host(pooley[1], [101 - I, I], None)
+    with pytest.raises(TypeError):   # a user observation model needs the source to live somewhere
+        dp.ModelDescriptor(dp.generate_custom_model("x", dp.RateFunction([dp.RateTerm(1, ((1,),))]), [1, 1], [[-1, 1]],
+                                                    obs_model=dp.SourceObsModel()), pooley)
+    orc.set_user_rates_from_source(SOURCE, str(tmp_path))   # leave the hooks as the other tests expect them
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [200, 3000])   # whole-filter kernel and multi-kernel path
+def test_user_obs_model_filter_matches_oracle(dp, orc, pooley, tmp_path, P):
+    orc.set_user_rates_from_source(SOURCE_OBS, str(tmp_path))
+    pf = dp.ParticleFilter(_model_obs(dp), pooley)
+    theta = np.array([[0.003, 0.0035], [0.1, 0.12], [0.01, 0.02], [0.02, 0.0]])
+    pop = pf.alloc_population(2, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=19)
+    for b in range(2):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=19, seg=b)
+        assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
+    pf.close()
+    orc.set_user_rates_from_source(SOURCE, str(tmp_path))
