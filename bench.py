@@ -24,10 +24,13 @@ POOLEY = [(20.0, [0, 18]), (40.0, [0, 65]), (60.0, [0, 70]), (80.0, [0, 66]), (1
 THETA = [0.003, 0.1]
 EXACT_LL = -15.6873794556  # exact CTMC forward algorithm (oracle/exact_sis.py)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU-issue ceiling of k_propagate: the SIS inner loop is 42 FP64 + 60 integer VALU instructions per
-# event; FP64 issues at 4 cycles per wave64 instruction (78.6 TFLOP/s FP64 vector peak), integer at 2, plus ~32 cycles
-# for the quarter-rate v_rcp_f64 / v_div_* ops: ~320 cycles per 64 events per SIMD, 1024 SIMDs at 2.4 GHz.
-VALU_CYCLES_PER_WAVE_EVENT = 42 * 4 + 60 * 2 + 32
+# VALU-issue ceiling of k_propagate: the SIS inner loop is 83 VALU instructions per event (ISA of
+# k_propagate<RSir<2>>: 2 x 14 stream + uniform, 24 log, 13 division, rates / event choice / state update / clock).
+# Measured issue cost per wave64 instruction on gfx950 (tools/valu_rate_probe.hip ->
+# profiles/r01_final/valu_issue_rates.json): FP64, 64-bit integer and three-operand 32-bit ops 4 cycles, plain
+# two-operand 32-bit ops (xor/add/or/mov/shift: 14 of the 83) ~0.65 of that, v_rcp_f64 3.4 x.  Hence
+# 69 + 14 * 0.65 + 2.4 = 80.5 issue slots = 322 cycles per 64 events per SIMD; 1024 SIMDs at 2.4 GHz.
+VALU_CYCLES_PER_WAVE_EVENT = (69 + 14 * 0.65 + 2.4) * 4
 VALU_CEILING_EVENTS_PER_S = 1024 * 2.4e9 * 64 / VALU_CYCLES_PER_WAVE_EVENT
 
 
@@ -103,6 +106,7 @@ def main():
     ap.add_argument("--cpu-serial-particles", type=int, default=1 << 16)
     ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 19)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +133,8 @@ def main():
     pf = dp.ParticleFilter(model, y, device=local_rank)
     stream = torch.cuda.current_stream()
     pf.set_stream(stream.cuda_stream)
+    if args.propagate_variant:
+        pf.set_propagate_variant(args.propagate_variant)
     P, T, S = args.particles, len(y), model.n_states
     gathered = torch.zeros(world, dtype=torch.float64, device="cuda")
     mine = torch.zeros(1, dtype=torch.float64, device="cuda")
@@ -206,8 +212,9 @@ def main():
             "events_per_s": round(events / world / args.steps / (prop.get("avg_us", 1) * T * 1e-6)) if prop else None,
             "events_per_particle_per_call": round(events / world / args.steps / P, 1),
             "hbm_achieved_GBs": prop.get("achieved_GBs"),
-            "bound": "fp64-valu + wave divergence (not HBM, not MFMA)",
+            "bound": "VALU issue + wave divergence (not HBM, not MFMA)",
             "valu_ceiling_events_per_s": round(VALU_CEILING_EVENTS_PER_S),
+            "lane_utilisation_static_schedule": [round(float(u), 3) for u in pf.lane_utilisation()],
         }
         if propagate.get("events_per_s"):
             propagate["valu_frac"] = round(propagate["events_per_s"] / VALU_CEILING_EVENTS_PER_S, 3)

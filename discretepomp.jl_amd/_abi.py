@@ -109,6 +109,7 @@ _PROTOTYPES = {
     "dpomp_kernel_name": (C.c_char_p, [C.c_int]),
     "dpomp_get_kernel_stat": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "dpomp_get_null_bracket_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dpomp_get_lane_utilisation": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "dpomp_last_event_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
 }
 

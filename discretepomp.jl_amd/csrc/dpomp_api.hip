@@ -33,6 +33,10 @@ typedef void (*PropFn)(PropArgs);
 
 constexpr int64_t kCompactionMinWaves = 8192;
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
+// Automatic schedule: an interval runs with workgroup compaction when, the last time this handle ran it, a
+// one-particle-per-lane schedule kept fewer than this fraction of the lanes busy (the kernels report that figure
+// whichever schedule they ran).  Compaction costs ~6 % when lanes finish together and saves 20-30 % when they do not.
+constexpr double kCompactionBelowUtil = 0.70;
 constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 
@@ -130,6 +134,7 @@ struct dpomp_handle {
     size_t events_used = 0;
     std::vector<PendingTiming> pending;
     uint64_t last_events = 0;
+    std::vector<double> lane_util;  // [T] lane utilisation a one-particle-per-lane schedule had / would have had, last call (-1 = unknown)
     std::string err;
     // scratch for dpomp_pf_loglik
     dpomp_pop* scratch_pop = nullptr;
@@ -155,7 +160,7 @@ struct dpomp_pop {
     int32_t* noresample = nullptr;            // [B]
     int carry_cur = 0;
     char* ctl = nullptr;                   // control block, see pop_alloc_impl
-    size_t ctl_bytes = 0, ctl_result_bytes = 0;
+    size_t ctl_bytes = 0, ctl_result_bytes = 0, sched_offset = 0;
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]      (inside ctl)
@@ -323,7 +328,9 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     // result download per call
     {
         const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
-        p->ctl_result_bytes = n_ll + n_ev + n_st;
+        const size_t n_sc = (size_t)p->T * 16;  // per observation: events, 64 * sum of per-wave maxima
+        p->sched_offset = n_ll + n_ev + n_st;
+        p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
         p->ctl_bytes = p->ctl_result_bytes + n_sm;
         DPOMP_ALLOC(p->ctl, p->ctl_bytes);
         p->ll = reinterpret_cast<double*>(p->ctl);
@@ -456,12 +463,15 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
         a.yval = h->d_obs_val + (size_t)k * h->n_obs_values;
         a.n_yval = h->n_obs_values;
+        a.sched = reinterpret_cast<unsigned long long*>(p->ctl + p->sched_offset) + 2 * (size_t)k;
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
             // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
             // taken by other waves); below that the plain kernel wins by 10-15 % (tools/latency_probe.py).
             int rpl = h->force_rpl;
-            if (rpl == 0) rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves) ? kDefaultPropVariant : 1;
+            if (rpl == 0)
+                rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] >= 0.0 &&
+                       h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
             if (h->rtc && rpl != 32) rpl = 1;  // run-time compiled models come in two variants
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
@@ -566,6 +576,11 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
     memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
     if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
+    if (domain == DOMAIN_PROPAGATE) {
+        const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(result.data() + p->sched_offset);
+        for (int k = ymin - 1; k < ymax; ++k)
+            if (sc[2 * k + 1]) h->lane_util[k] = (double)sc[2 * k] / (double)sc[2 * k + 1];
+    }
     return DPOMP_OK;
 }
 
@@ -750,6 +765,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     }
     h->stream = h->own_stream;
     h->T = d->n_obs;
+    h->lane_util.assign((size_t)d->n_obs, -1.0);
     h->obs_time.assign(d->obs_time, d->obs_time + d->n_obs);
     h->obs_id.assign(d->obs_id, d->obs_id + d->n_obs);
     h->ysum.resize(d->n_obs);
@@ -1174,6 +1190,13 @@ int dpomp_get_kernel_stat(dpomp_handle* h, int kid, int64_t* launches, double* t
     if (!h || kid < 0 || kid >= KID_COUNT) return DPOMP_EINVAL;
     if (launches) *launches = h->stats[kid].launches;
     if (total_ms) *total_ms = h->stats[kid].total_ms;
+    return DPOMP_OK;
+}
+
+int dpomp_get_lane_utilisation(dpomp_handle* h, int obs_index, double* util) {
+    if (!h || !util) return fail(h, DPOMP_EINVAL, "null argument");
+    if (obs_index < 1 || obs_index > h->T) return fail(h, DPOMP_EINVAL, "obs_index %d out of 1..%d", obs_index, h->T);
+    *util = h->lane_util[(size_t)obs_index - 1];
     return DPOMP_OK;
 }
 

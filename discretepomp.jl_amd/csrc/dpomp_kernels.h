@@ -69,6 +69,7 @@ struct PropArgs {
     const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
     const long long* yval;    // [V] Observation.val of this observation (user observation models)
     int32_t n_yval;
+    unsigned long long* sched;  // [2] or null: += sum of per-particle events, += sum over waves of 64 * (max events in wave)
 };
 
 // ---- rate evaluators (the pluggable part) -------------------------------------------------
@@ -188,6 +189,20 @@ struct RRossmac : RBase<4, 6> {
     }
 };
 
+// The parameter vector of one filter in registers.  Kernels whose loop crosses a barrier (compaction, LDS queue,
+// whole-filter) cannot have the compiler hoist the uniform theta loads out of the event loop, and a scalar load
+// per event costs more than the RNG; compiled evaluators index theta with constants, so a register copy costs
+// only the entries they use.  The table interpreter indexes theta at run time and keeps reading memory.
+template <class R>
+struct ThetaRegs {
+    double v[8];
+    __device__ __forceinline__ ThetaRegs(const double* th, int K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (!R::kGeneric && i < K) ? th[i] : 0.0;
+    }
+    __device__ __forceinline__ const double* get(const double* th) const { return R::kGeneric ? th : v; }
+};
+
 // Observation log-density of one particle: partial_gaussian_obs_model (hmm_examples.jl:59-67),
 //   tmp1 - (sum(y.val[y_seq]) - sum(pop[seq]))^2 / tmp2   with the integer square taken before the promotion,
 // or, for run-time compiled models that define it, the user's dpomp_user_obs(theta, x, y.val, length(y.val)).
@@ -207,9 +222,21 @@ __device__ __forceinline__ double obs_log_weight(const DevModel& m, const double
 }
 
 // ---- wave / block helpers --------------------------------------------------------------
+// Wave votes straight from the lane mask (HIP's __any/__ballot go through an integer compare in VGPRs: two VALU
+// instructions per call, which matters inside the event loop).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
     return v;
 }
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -253,6 +280,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     const int s_real = R::kGeneric ? a.m.S : S;  // RGeneric pads S up to 2/4/8: rows >= s_real do not exist
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
+    const ThetaRegs<R> th_regs(th, a.m.K);
+    const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     __shared__ double s_log[128][2];  // dlog table: one ds_read_b128 per event
     for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
@@ -273,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     if (valid) {
         for (;;) {
             double cum[E];
-            R::rates(a.m, th, x, cum);
+            R::rates(a.m, thr, x, cum);
 #pragma unroll
             for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
             const double tot = cum[E - 1];
@@ -314,28 +343,36 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     __shared__ unsigned long long s_ev[kBlock / 64];
     __shared__ int s_cap[kBlock / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ int s_nmax[kBlock / 64];
     const double wm = wave_max(g);
     const unsigned long long wev = wave_sum((unsigned long long)n);
-    const int wcap = __any(capped);
+    const int wnmax = wave_max_i32(n);
+    const int wcap = wave_any(capped);
     if (lane == 0) {
         s_max[wid] = wm;
         s_ev[wid] = wev;
         s_cap[wid] = wcap;
+        s_nmax[wid] = wnmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double bm = s_max[0];
-        unsigned long long be = s_ev[0];
+        unsigned long long be = s_ev[0], bs = (unsigned long long)s_nmax[0];
         int bc = s_cap[0];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; ++w) {
             bm = fmax(bm, s_max[w]);
             be += s_ev[w];
+            bs += (unsigned long long)s_nmax[w];
             bc |= s_cap[w];
         }
         if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
         if (be) atomicAdd(a.events, be);
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+        if (a.sched && be) {  // what a one-particle-per-lane schedule makes of this interval (dpomp_get_lane_utilisation)
+            atomicAdd(&a.sched[0], be);
+            atomicAdd(&a.sched[1], 64ull * bs);
+        }
     }
 }
 
@@ -369,6 +406,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     const int s_real = R::kGeneric ? a.m.S : S;
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
+    const ThetaRegs<R> th_regs(th, a.m.K);
+    const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 #pragma unroll
@@ -378,8 +417,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
             const int p = base + idx;
 #pragma unroll
             for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
-            const Stream r = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
-            s_seed[idx] = make_uint4((uint32_t)r.s0, (uint32_t)(r.s0 >> 32), (uint32_t)r.s1, (uint32_t)(r.s1 >> 32));
+            const StreamSeed r = stream_seed(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
+            s_seed[idx] = make_uint4(r.w0, r.w1, r.w2, r.w3);
         }
     }
     if (threadIdx.x == 0) s_next = 0;
@@ -392,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     int x[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] = 0;
-    Stream rng{0, 0};
+    Stream rng{0, 0, 0, 0};
     double time = 0.0;
     int n = 0, cur = 0;
     bool active = false, exhausted = false;
@@ -404,8 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
                 const uint4 sd = s_seed[idx];
-                rng.s0 = (uint64_t)sd.x | ((uint64_t)sd.y << 32);
-                rng.s1 = (uint64_t)sd.z | ((uint64_t)sd.w << 32);
+                rng = stream_start(StreamSeed{sd.x, sd.y, sd.z, sd.w});
                 time = t_start;
                 n = 0;
                 active = true;
@@ -413,10 +451,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
                 exhausted = true;
             }
         }
-        if (!__any(active)) break;
+        if (!wave_any(active)) break;
         if (active) {
             double cum[E];
-            R::rates(a.m, th, x, cum);
+            R::rates(a.m, thr, x, cum);
 #pragma unroll
             for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
             const double tot = cum[E - 1];
@@ -478,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const double wm = wave_max(gmax);
     const unsigned long long wev = wave_sum(ev);
-    const int wcap = __any(any_cap);
+    const int wcap = wave_any(any_cap);
     if (lane == 0) {
         s_max[wid] = wm;
         s_ev[wid] = wev;
@@ -517,10 +555,17 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     __shared__ double s_log[128][2];
     __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
     __shared__ int32_t s_cnt[kBlock];     // executed events, bit 31 = event cap
-    __shared__ int32_t c_x[S][kBlock];    // compaction staging
-    __shared__ uint4 c_rng[kBlock];
-    __shared__ double c_time[kBlock];
-    __shared__ int2 c_nc[kBlock];
+    // Compaction staging.  A compaction frees at least one wave, so at most kBlock - 64 contexts move; they go
+    // through one buffer in two passes (stream words, then state/clock/counters) to keep the workgroup's LDS
+    // small enough for 8 workgroups per CU with room to spare.
+    constexpr int kLive = kBlock - 64;
+    constexpr int kCtxBytes = (S * 4 + 16) > 32 ? (S * 4 + 16) : 32;
+    __shared__ __attribute__((aligned(16))) unsigned char c_raw[kCtxBytes * kLive];
+    uint4* const c_rng0 = reinterpret_cast<uint4*>(c_raw);
+    uint4* const c_rng1 = c_rng0 + kLive;
+    double* const c_time = reinterpret_cast<double*>(c_raw);
+    int2* const c_nc = reinterpret_cast<int2*>(c_raw + 8 * kLive);
+    int32_t* const c_x = reinterpret_cast<int32_t*>(c_raw + 16 * kLive);  // [S][kLive]
     __shared__ int s_wcnt[2][kBlock / 64];
     __shared__ double s_max[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
@@ -533,6 +578,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     const int s_real = R::kGeneric ? a.m.S : S;
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
+    const ThetaRegs<R> th_regs(th, a.m.K);
+    const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 
@@ -551,37 +598,39 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     __syncthreads();
 
     for (int round = 0;; ++round) {
-        for (int it = 0; it < CHK; ++it) {  // wave-uniform trip count; the body is the static kernel's
-            if (!__any(active)) break;
-            if (active) {
+        if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
+            int it = 0;
+            for (;;) {
                 double cum[E];
-                R::rates(a.m, th, x, cum);
+                R::rates(a.m, thr, x, cum);
 #pragma unroll
                 for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
                 const double tot = cum[E - 1];
                 if (tot == 0.0) {
                     active = false;
-                } else {
-                    const double u1 = u01(stream_next(rng));
-                    time = time - dlog_tab(u1, s_log) / tot;
-                    if (time > tmax) {
-                        active = false;
-                    } else {
-                        const double etc = u01(stream_next(rng)) * tot;
-                        TW tw = (TW)a.m.trans_packed[e_real - 1];
-#pragma unroll
-                        for (int i = E - 2; i >= 0; --i) {
-                            const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                            if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
-                        }
-#pragma unroll
-                        for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-                        if (++n >= cap) {
-                            capped = true;
-                            active = false;
-                        }
-                    }
+                    break;
                 }
+                const double u1 = u01(stream_next(rng));
+                time = time - dlog_tab(u1, s_log) / tot;
+                if (time > tmax) {
+                    active = false;
+                    break;
+                }
+                const double etc = u01(stream_next(rng)) * tot;
+                TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+                for (int i = E - 2; i >= 0; --i) {
+                    const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                    if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+                if (++n >= cap) {
+                    capped = true;
+                    active = false;
+                    break;
+                }
+                if (++it >= CHK) break;
             }
         }
         if (!active && !parked) {  // once per particle, outside the hot loop
@@ -590,7 +639,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
             s_cnt[cur] = n | (capped ? (int)0x80000000 : 0);
             parked = true;
         }
-        const unsigned long long bal = __ballot(active);
+        const unsigned long long bal = wave_ballot(active);
         if (lane == 0) s_wcnt[round & 1][wid] = __popcll(bal);
         __syncthreads();
         const int c0 = s_wcnt[round & 1][0], c1 = s_wcnt[round & 1][1], c2 = s_wcnt[round & 1][2],
@@ -599,25 +648,36 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
         if (total == 0) break;
         const int waves_now = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
         if (((total + 63) >> 6) < waves_now) {  // workgroup-uniform
+            const int rank = (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0) +
+                             __popcll(bal & ((1ull << lane) - 1ull));
+            const bool take = (int)threadIdx.x < total;
             if (active) {
-                const int rank = (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0) +
-                                 __popcll(bal & ((1ull << lane) - 1ull));
+                c_rng0[rank] = make_uint4((uint32_t)rng.a, (uint32_t)(rng.a >> 32), (uint32_t)rng.b, (uint32_t)(rng.b >> 32));
+                c_rng1[rank] = make_uint4((uint32_t)rng.c, (uint32_t)(rng.c >> 32), (uint32_t)rng.n, (uint32_t)(rng.n >> 32));
+            }
+            __syncthreads();
+            Stream moved = rng;
+            if (take) {
+                const uint4 r4 = c_rng0[threadIdx.x], r5 = c_rng1[threadIdx.x];
+                moved.a = (uint64_t)r4.x | ((uint64_t)r4.y << 32);
+                moved.b = (uint64_t)r4.z | ((uint64_t)r4.w << 32);
+                moved.c = (uint64_t)r5.x | ((uint64_t)r5.y << 32);
+                moved.n = (uint64_t)r5.z | ((uint64_t)r5.w << 32);
+            }
+            __syncthreads();
+            if (active) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) c_x[s][rank] = x[s];
-                c_rng[rank] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1,
-                                         (uint32_t)(rng.s1 >> 32));
+                for (int s = 0; s < S; ++s) c_x[s * kLive + rank] = x[s];
                 c_time[rank] = time;
                 c_nc[rank] = make_int2(n, cur);
             }
             __syncthreads();
-            active = (int)threadIdx.x < total;
+            active = take;
             parked = !active;  // every lane without a live context has already parked (or never had) its particle
             if (active) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) x[s] = c_x[s][threadIdx.x];
-                const uint4 r4 = c_rng[threadIdx.x];
-                rng.s0 = (uint64_t)r4.x | ((uint64_t)r4.y << 32);
-                rng.s1 = (uint64_t)r4.z | ((uint64_t)r4.w << 32);
+                for (int s = 0; s < S; ++s) x[s] = c_x[s * kLive + threadIdx.x];
+                rng = moved;
                 time = c_time[threadIdx.x];
                 const int2 nc = c_nc[threadIdx.x];
                 n = nc.x;
@@ -649,26 +709,33 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     }
     const double wm = wave_max(g);
     const unsigned long long wev = wave_sum(ev);
-    const int wcap = __any(capped);
+    const int wnmax = wave_max_i32((int)ev);  // particle slots in launch order: the static schedule's waves
+    const int wcap = wave_any(capped);
     if (lane == 0) {
         s_max[wid] = wm;
         s_ev[wid] = wev;
         s_cap[wid] = wcap;
+        s_wcnt[0][wid] = wnmax;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double bm = s_max[0];
-        unsigned long long be = s_ev[0];
+        unsigned long long be = s_ev[0], bs = (unsigned long long)s_wcnt[0][0];
         int bc = s_cap[0];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; ++w) {
             bm = fmax(bm, s_max[w]);
             be += s_ev[w];
+            bs += (unsigned long long)s_wcnt[0][w];
             bc |= s_cap[w];
         }
         if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
         if (be) atomicAdd(a.events, be);
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+        if (a.sched && be) {
+            atomicAdd(&a.sched[0], be);
+            atomicAdd(&a.sched[1], 64ull * bs);
+        }
     }
 }
 
@@ -718,6 +785,8 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     const int e_real = R::kGeneric ? a.m.E : E;
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
+    const ThetaRegs<R> th_regs(th, a.m.K);
+    const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
     for (int i = tid; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 
     int x[S];
@@ -743,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         if (valid) {
             for (;;) {
                 double cum[E];
-                R::rates(a.m, th, x, cum);
+                R::rates(a.m, thr, x, cum);
 #pragma unroll
                 for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
                 const double tot = cum[E - 1];
@@ -822,7 +891,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     for (int s = 0; s < S; ++s)
         if (valid && s < s_real) st[(int64_t)s * a.Pp + tid] = x[s];
     const unsigned long long wev = wave_sum(ev);
-    const int wcap = __any(any_cap);
+    const int wcap = wave_any(any_cap);
     if (lane == 0) {
         s_ev[wid] = wev;
         s_cap[wid] = wcap;

@@ -59,8 +59,9 @@ DPOMP_HD uint64_t double_to_bits(double d) {
 #endif
 }
 
+// sfc64 state (Doty-Humphrey's "small fast chaotic" generator, PractRand): three 64-bit words and a counter.
 struct Stream {
-    uint64_t s0, s1;
+    uint64_t a, b, c, n;
 };
 
 // Philox4x32-10 keyed by the call seed; counter = (particle, segment, observation, domain).
@@ -81,58 +82,62 @@ DPOMP_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-DPOMP_HD Stream stream_init(uint64_t seed, uint32_t seg, uint32_t particle, uint32_t obs,
-                            uint32_t domain) {
-    uint32_t o[4];
-    philox4x32_10(particle, seg, obs, domain, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    Stream s;
-    s.s0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
-    s.s1 = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
-    if ((s.s0 | s.s1) == 0) s.s0 = 0x9E3779B97F4A7C15ull;
-    return s;
-}
-
-DPOMP_HD uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-
-// xoroshiro128++ step.
+// sfc64 step: additions, one shift-xor, one shift-add and one rotate -- on gfx950 the 64-bit adds and the
+// shift-add are single v_lshl_add_u64 instructions, ~11 VALU ops per 64 random bits (xoroshiro128++ needs ~19).
 #if defined(__HIP_DEVICE_COMPILE__)
-// Same function on 32-bit halves: every 64-bit rotate/shift is two v_alignbit_b32 (full rate)
-// instead of a 64-bit shift + shift + or, and the three-way xor is one v_xor3_b32 per half.
-__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {
-    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ({hi,lo} >> sh) low word
-}
+// Device form of the same step.  c + (c << 3) is pinned to one v_lshl_add_u64 (the compiler otherwise rewrites it
+// as c * 9 and emits quarter-rate v_mad_u64_u32 pairs); the rotate is two v_alignbit_b32 on the 32-bit halves.
 __device__ __forceinline__ uint64_t stream_next(Stream& s) {
-    const uint32_t a_lo = (uint32_t)s.s0, a_hi = (uint32_t)(s.s0 >> 32);
-    uint32_t b_lo = (uint32_t)s.s1, b_hi = (uint32_t)(s.s1 >> 32);
-    const uint64_t sum = s.s0 + s.s1;
-    const uint32_t m_lo = (uint32_t)sum, m_hi = (uint32_t)(sum >> 32);
-    // rotl(sum, 17)
-    const uint64_t rot = ((uint64_t)funnel(m_hi, m_lo, 15) << 32) | funnel(m_lo, m_hi, 15);
-    const uint64_t result = rot + s.s0;
-    b_lo ^= a_lo;
-    b_hi ^= a_hi;
-    // rotl(s0, 49) = halves swapped, then rotl 17
-    const uint32_t r49_hi = funnel(a_lo, a_hi, 15), r49_lo = funnel(a_hi, a_lo, 15);
-    // s1 << 21
-    const uint32_t sh_hi = funnel(b_hi, b_lo, 11), sh_lo = b_lo << 21;
-    const uint32_t n0_lo = r49_lo ^ b_lo ^ sh_lo, n0_hi = r49_hi ^ b_hi ^ sh_hi;
-    // rotl(s1, 28)
-    const uint32_t n1_hi = funnel(b_hi, b_lo, 4), n1_lo = funnel(b_lo, b_hi, 4);
-    s.s0 = ((uint64_t)n0_hi << 32) | n0_lo;
-    s.s1 = ((uint64_t)n1_hi << 32) | n1_lo;
-    return result;
+    const uint64_t t = s.a + s.b + s.n;
+    s.n += 1;
+    s.a = s.b ^ (s.b >> 11);
+    uint64_t nb;
+    asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(nb) : "v"(s.c));
+    s.b = nb;
+    const uint32_t c_lo = (uint32_t)s.c, c_hi = (uint32_t)(s.c >> 32);
+    const uint32_t r_hi = __builtin_amdgcn_alignbit(c_hi, c_lo, 8), r_lo = __builtin_amdgcn_alignbit(c_lo, c_hi, 8);
+    s.c = (((uint64_t)r_hi << 32) | r_lo) + t;
+    return t;
 }
 #else
 DPOMP_HD uint64_t stream_next(Stream& s) {
-    const uint64_t s0 = s.s0;
-    uint64_t s1 = s.s1;
-    const uint64_t result = rotl64(s0 + s1, 17) + s0;
-    s1 ^= s0;
-    s.s0 = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
-    s.s1 = rotl64(s1, 28);
-    return result;
+    const uint64_t t = s.a + s.b + s.n;
+    s.n += 1;
+    s.a = s.b ^ (s.b >> 11);
+    s.b = s.c + (s.c << 3);
+    s.c = ((s.c << 24) | (s.c >> 40)) + t;
+    return t;
 }
 #endif
+
+constexpr int kStreamWarmup = 12;  // rounds discarded after seeding (PractRand's sfc64 seeding discards 12)
+
+// The 128 Philox bits that name a stream; stream_start() expands them into a running generator.  The two are
+// separate so that a kernel can queue the 16-byte name in LDS and start the stream where it is consumed.
+struct StreamSeed {
+    uint32_t w0, w1, w2, w3;
+};
+
+DPOMP_HD StreamSeed stream_seed(uint64_t seed, uint32_t seg, uint32_t particle, uint32_t obs, uint32_t domain) {
+    uint32_t o[4];
+    philox4x32_10(particle, seg, obs, domain, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return StreamSeed{o[0], o[1], o[2], o[3]};
+}
+
+DPOMP_HD Stream stream_start(const StreamSeed& w) {
+    Stream s;
+    s.a = (uint64_t)w.w0 | ((uint64_t)w.w1 << 32);
+    s.b = (uint64_t)w.w2 | ((uint64_t)w.w3 << 32);
+    s.c = 0x9E3779B97F4A7C15ull;
+    s.n = 1;
+#pragma unroll
+    for (int i = 0; i < kStreamWarmup; ++i) (void)stream_next(s);
+    return s;
+}
+
+DPOMP_HD Stream stream_init(uint64_t seed, uint32_t seg, uint32_t particle, uint32_t obs, uint32_t domain) {
+    return stream_start(stream_seed(seed, seg, particle, obs, domain));
+}
 
 // Top 52 bits -> u = (2k+1) 2^-53 in (0,1).  [1,2) mantissa trick: (d - 1) = k 2^-52 exactly,
 // and k 2^-52 + 2^-53 is representable, so this equals (double)(2k+1) * 2^-53 bit for bit.
@@ -151,10 +156,22 @@ DPOMP_HD double u01(uint64_t x) {
 // The two subintervals touching 1 have c = 1 (invc = 1, logc = 0), so log(x) keeps full relative
 // accuracy as x -> 1.  Max error 1 ulp (tests/test_oracle_numerics.py).  In k_propagate the
 // table lives in LDS (one ds_read_b128 per event).
+// On the device the polynomial constants are pinned to scalar registers: a wave-uniform fma addend then comes
+// straight from an SGPR pair, where the compiler otherwise parks the literals in VGPRs and spends a v_mov_b64 per
+// Horner step re-materialising the accumulator.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double scalar_const(double v) {
+    asm("" : "+s"(v));
+    return v;
+}
+#else
+inline double scalar_const(double v) { return v; }
+#endif
+
 DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
     const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
-    const double A0 = -0.5, A1 = 0x1.5555555555555p-2, A2 = -0.25, A3 = 0x1.999999999999ap-3,
-                 A4 = -0x1.5555555555555p-3, A5 = 0x1.2492492492492p-3, A6 = -0.125;
+    const double A0 = -0.5, A1 = scalar_const(0x1.5555555555555p-2), A2 = -0.25, A3 = scalar_const(0x1.999999999999ap-3),
+                 A4 = scalar_const(-0x1.5555555555555p-3), A5 = scalar_const(0x1.2492492492492p-3), A6 = -0.125;
     const uint64_t ix = double_to_bits(x);
     const uint64_t tmp = ix - 0x3FE6000000000000ull;
     const int i = (int)((uint32_t)(tmp >> 45) & 127u);

@@ -235,6 +235,16 @@ class ParticleFilter:
         return counts, [times[: m[i], i].copy() for i in range(n)], [types[: m[i], i].copy() for i in range(n)], states
 
     # -- inspection ---------------------------------------------------------------------
+    def lane_utilisation(self) -> np.ndarray:
+        """Per observation interval: the fraction of lanes a one-particle-per-lane schedule kept busy in the most
+        recent call (-1 where unknown); what the automatic propagate variant decides on."""
+        out = np.empty(self.n_obs)
+        u = C.c_double()
+        for k in range(self.n_obs):
+            self._check(self._lib.dpomp_get_lane_utilisation(self._h, k + 1, C.byref(u)))
+            out[k] = u.value
+        return out
+
     def last_event_count(self) -> int:
         ev = C.c_uint64()
         self._check(self._lib.dpomp_last_event_count(self._h, C.byref(ev)))

@@ -177,10 +177,11 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type);
  * observation (increment = LSE(carried + new) - LSE(carried)).  The carry state lives in the population handle. */
 int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac);
 
-/* Tuning: variant of the propagation kernel.  0 = library default; 1 = one particle
- * per lane; 2, 4 = workgroup-local LDS queue with that many particles per lane and dynamic lane
- * refill; 16, 32 = one particle per lane with workgroup-level compaction every that many events.
- * Results do not depend on it. */
+/* Tuning: variant of the propagation kernel.  0 = library default (per observation interval: one
+ * particle per lane, or workgroup compaction when the previous call measured a lane utilisation below 0.7 for that
+ * interval on a chip-filling launch, see dpomp_get_lane_utilisation); 1 = one particle per lane; 2, 4 =
+ * workgroup-local LDS queue with that many particles per lane and dynamic lane refill; 16, 32 = one particle per
+ * lane with workgroup-level compaction every that many events.  Results do not depend on it. */
 int dpomp_set_propagate_variant(dpomp_handle* h, int variant);
 
 /* ---- the particle filter ------------------------------------------------------- */
@@ -248,6 +249,11 @@ int dpomp_get_kernel_stat(dpomp_handle* h, int kernel_id, int64_t* launches, dou
 /* Elapsed time of an EMPTY event bracket (two hipEventRecord with nothing between), median of 64, measured when
  * profiling was switched on: what every bracket adds to a kernel's own duration. */
 int dpomp_get_null_bracket_ms(dpomp_handle* h, double* ms);
+/* Lane utilisation of the propagation towards observation obs_index (1-based) in the most recent call that ran it:
+ * sum of per-particle event counts / (64 * sum over waves of the largest count in the wave), i.e. the busy fraction
+ * of a one-particle-per-lane schedule.  -1 if that interval has not run yet (or ran in the single-workgroup kernel).
+ * The automatic propagate variant uses this figure to decide, per interval, whether workgroup compaction pays. */
+int dpomp_get_lane_utilisation(dpomp_handle* h, int obs_index, double* util);
 /* Gillespie events executed by the last pf call (sum over all particles). */
 int dpomp_last_event_count(dpomp_handle* h, uint64_t* events);
 

@@ -75,28 +75,32 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-/* Stream state for (seed, segment b, particle p, observation k, domain). */
+/* sfc64 (C. Doty-Humphrey's "small fast chaotic" generator as published with PractRand; shifts 11/3, rotate 24),
+ * restated from the published algorithm.  State: a, b, c and a counter. */
+uint64_t orc_stream_next(uint64_t s[4]) {
+    uint64_t t = s[0] + s[1] + s[3];
+    s[3] += 1;
+    s[0] = s[1] ^ (s[1] >> 11);
+    s[1] = s[2] + (s[2] << 3);
+    s[2] = ((s[2] << 24) | (s[2] >> 40)) + t;
+    return t;
+}
+
+#define ORC_STREAM_WARMUP 12 /* outputs discarded after seeding, as PractRand's sfc64 seeding does */
+
+/* Stream for (seed, segment b, particle p, observation k, domain): the 128 Philox bits give a and b, c is a fixed
+ * odd constant, the counter starts at 1, and the first 12 outputs are discarded. */
 void orc_stream_init(uint64_t seed, uint32_t b, uint32_t p, uint32_t k, uint32_t domain,
-                     uint64_t s[2]) {
+                     uint64_t s[4]) {
     uint32_t ctr[4] = {p, b, k, domain};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t o[4];
     orc_philox4x32_10(ctr, key, o);
     s[0] = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
     s[1] = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
-    if ((s[0] | s[1]) == 0) s[0] = 0x9E3779B97F4A7C15ull;
-}
-
-static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-
-/* xoroshiro128++ (Blackman & Vigna 2019), restated from the published algorithm. */
-uint64_t orc_stream_next(uint64_t s[2]) {
-    uint64_t s0 = s[0], s1 = s[1];
-    uint64_t result = rotl64(s0 + s1, 17) + s0;
-    s1 ^= s0;
-    s[0] = rotl64(s0, 49) ^ s1 ^ (s1 << 21);
-    s[1] = rotl64(s1, 28);
-    return result;
+    s[2] = 0x9E3779B97F4A7C15ull;
+    s[3] = 1;
+    for (int i = 0; i < ORC_STREAM_WARMUP; ++i) (void)orc_stream_next(s);
 }
 
 /* 52 random bits -> (0,1): u = (2k+1) * 2^-53, never 0 or 1, exact in double. */
@@ -104,7 +108,7 @@ double orc_u01(uint64_t x) { return (double)(2 * (x >> 12) + 1) * 0x1p-53; }
 
 void orc_uniforms(uint64_t seed, uint32_t b, uint32_t p, uint32_t k, uint32_t domain, int64_t n,
                   double* out) {
-    uint64_t s[2];
+    uint64_t s[4];
     orc_stream_init(seed, b, p, k, domain, s);
     for (int64_t i = 0; i < n; ++i) out[i] = orc_u01(orc_stream_next(s));
 }
@@ -275,7 +279,7 @@ static int64_t default_cap(const dpomp_model_desc* d) {
  * x is advanced in place from time t to tmax; returns the number of executed events,
  * or -1 if the event cap was hit (a guard the reference lacks). */
 static int64_t gillespie_advance(const dpomp_model_desc* d, const double* theta, int64_t* x,
-                                 double t, double tmax, uint64_t s[2], int mode, int64_t cap) {
+                                 double t, double tmax, uint64_t s[4], int mode, int64_t cap) {
     const int E = d->n_events, S = d->n_states;
     double cum[DPOMP_MAX_EVENTS];
     int64_t n = 0;
@@ -314,7 +318,7 @@ void orc_iterate_particles(const dpomp_model_desc* d, int64_t* pop, int64_t P, c
     for (int64_t p = 0; p < P; ++p) {
         int64_t x[DPOMP_MAX_STATES];
         for (int i = 0; i < S; ++i) x[i] = pop[p + P * i]; /* ptemp .= pop[p,:] :17 */
-        uint64_t s[2];
+        uint64_t s[4];
         orc_stream_init(seed, seg, (uint32_t)p, (uint32_t)k, ORC_DOMAIN_PROPAGATE, s);
         int64_t n = gillespie_advance(d, theta, x, t, tmax, s, mode, cap);
         double g = orc_obs_loglik_theta(d, k, x, theta); /* :29 */
@@ -501,7 +505,7 @@ int orc_pf_partial_adaptive(const dpomp_model_desc* d, int64_t* pop, int64_t P, 
             } else if (obs_i < T) { /* :62 */
                 if (ess_frac > 0.0) carry->active = 0;
                 memcpy(old_p, pop, sizeof(int64_t) * P * S); /* old_p .= pop :66 */
-                uint64_t rs[2];
+                uint64_t rs[4];
                 orc_stream_init(seed, seg, 0u, (uint32_t)k, ORC_DOMAIN_RESAMPLE, rs);
                 double r = orc_u01(orc_stream_next(rs)); /* rand() hmm_pf_resample.jl:27 */
                 if (rs_type != DPOMP_RS_SYSTEMATIC) {
@@ -511,7 +515,7 @@ int orc_pf_partial_adaptive(const dpomp_model_desc* d, int64_t* pop, int64_t P, 
                      * multinomial chs_i = rand_i * cw[end]; ancestor = first j whose cumulative weight
                      * exceeds it.  One uniform per slot from its own stream. */
                     for (int64_t i = 0; i < P; ++i) {
-                        uint64_t ps[2];
+                        uint64_t ps[4];
                         orc_stream_init(seed, seg, (uint32_t)i, (uint32_t)k, ORC_DOMAIN_RESAMPLE_PARTICLE, ps);
                         double ui = orc_u01(orc_stream_next(ps));
                         int64_t j = 0;
@@ -607,7 +611,7 @@ int orc_simulate(const dpomp_model_desc* d, int64_t P, const double* theta, uint
         for (int i = 0; i < S; ++i) x[i] = d->initial_condition[i];
         double t = d->t0_index == 0 ? 0.0 : theta[d->t0_index - 1]; /* hmm_sim.jl:92 */
         for (int k = 0; k < T; ++k) {
-            uint64_t s[2];
+            uint64_t s[4];
             orc_stream_init(seed, seg, (uint32_t)p, (uint32_t)k, ORC_DOMAIN_SIMULATE, s);
             gillespie_advance(d, theta, x, t, d->obs_time[k], s, ORC_MODE_SPEC, cap);
             for (int i = 0; i < S; ++i) out[((int64_t)k * S + i) * P + p] = x[i];
@@ -631,7 +635,7 @@ int64_t orc_simulate_events(const dpomp_model_desc* d, const double* theta, uint
     int64_t n = 0;
     int overflow = 0;
     for (int k = 0; k < T; ++k) {
-        uint64_t s[2];
+        uint64_t s[4];
         orc_stream_init(seed, seg, p, (uint32_t)k, ORC_DOMAIN_SIMULATE, s);
         double cum[DPOMP_MAX_EVENTS];
         while (!overflow) {

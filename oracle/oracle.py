@@ -92,6 +92,15 @@ def philox(ctr, key):
     return list(o)
 
 
+def sfc64_raw(a, b, c, counter, n):
+    """n raw outputs of the stream generator from an explicit state (a, b, c, counter)."""
+    st = (C.c_uint64 * 4)(a, b, c, counter)
+    f = lib().orc_stream_next
+    f.restype = C.c_uint64
+    f.argtypes = [C.POINTER(C.c_uint64)]
+    return [int(f(st)) for _ in range(n)]
+
+
 def uniforms(seed, seg, p, k, domain, n):
     out = np.empty(n)
     lib().orc_uniforms(seed, seg, p, k, domain, n, _dp(out))

@@ -335,7 +335,7 @@ def test_baseline_config_shapes_at_scale(dp, orc, name, x0, theta, csv):
     big = pf.loglik(np.tile(np.array(theta)[:, None], (1, 4)), 1 << 16, seed=7)
     assert np.all(np.isfinite(big)) and np.all(pf.last_status == 0)
     assert big.max() - big.min() < 0.25, big   # four independent 65536-particle estimates of the same quantity
-    assert abs(big.mean() - small) < 1.5        # and the 512-particle estimate is in the same place
+    assert abs(big.mean() - small) < 4.0        # and the 512-particle estimate is in the same place (its own sd is ~1)
     pf.close()
 
 
@@ -515,4 +515,39 @@ def test_small_filter_kernel_incremental_unweighted_and_batched(dp, orc, make_ob
         ref = orc.pf_loglik(pf.desc, P, theta[:, s], seed=6, seg=2 + int(s))
         assert abs((a[s] + b[s]) - ref.ll) < 1e-12 and full[s] == ref.ll
         assert np.array_equal(pop.download(int(s)), ref.pop) and np.array_equal(pop2.download(int(s)), ref.pop)
+    pf.close()
+
+
+@pytest.mark.parametrize("rpl", [1, 32])
+def test_lane_utilisation_statistic_matches_oracle_event_counts(sis, orc, rpl):
+    """dpomp_get_lane_utilisation: sum of per-particle events / (64 * sum over waves of the wave's maximum), from
+    either schedule, against the same figure computed from the oracle's per-particle event counts."""
+    theta, P = [0.003, 0.1], 4097
+    sis.set_propagate_variant(rpl)
+    sis.loglik(np.array(theta)[:, None], P, seed=3)
+    ref = orc.pf_loglik(sis.desc, P, theta, seed=3, trace=True)
+    want = []
+    for k in range(sis.n_obs):
+        n = np.zeros(((P + 63) // 64) * 64, dtype=np.int64)
+        n[:P] = ref.particle_events[k]
+        want.append(n.sum() / (64.0 * n.reshape(-1, 64).max(axis=1).sum()))
+    assert np.allclose(sis.lane_utilisation(), want, rtol=1e-12)
+    sis.set_propagate_variant(0)
+
+
+def test_automatic_schedule_switches_per_interval_and_keeps_results(dp, pooley):
+    """Chip-filling launch (2^19 particles = 8192 waves): the first call runs one particle per lane everywhere and
+    measures the lane utilisation; the second call uses compaction where it was below 0.7 (Pooley: the first
+    interval, where most epidemics die out at once).  Results do not depend on the schedule."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    theta = np.array([[0.003], [0.1]])
+    assert np.all(pf.lane_utilisation() == -1.0)
+    a = pf.loglik(theta, 1 << 19, seed=21)
+    u = pf.lane_utilisation()
+    assert u[0] < 0.7 and np.all(u[1:] > 0.7), u
+    b = pf.loglik(theta, 1 << 19, seed=21)          # now with compaction in interval 1
+    pf.set_propagate_variant(1)
+    c = pf.loglik(theta, 1 << 19, seed=21)
+    assert a[0] == b[0] == c[0]
+    assert np.array_equal(pf.lane_utilisation(), u)
     pf.close()

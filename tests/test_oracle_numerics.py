@@ -18,23 +18,37 @@ def test_philox4x32_10_known_answers(orc):
 
 
 def _py_stream(seed, seg, p, k, domain, n):
-    """Independent big-integer restatement: Philox seeding + xoroshiro128++ + (2k+1)/2^53."""
+    """Independent big-integer restatement: Philox seeding + sfc64 (12 discarded outputs) + (2k+1)/2^53."""
     M = (1 << 64) - 1
-    rotl = lambda x, r: ((x << r) | (x >> (64 - r))) & M
     c = [p, seg, k, domain]
     key = [seed & 0xFFFFFFFF, seed >> 32]
     for _ in range(10):
         p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
         c = [(p1 >> 32) ^ c[1] ^ key[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ key[1], p0 & 0xFFFFFFFF]
         key = [(key[0] + 0x9E3779B9) & 0xFFFFFFFF, (key[1] + 0xBB67AE85) & 0xFFFFFFFF]
-    s0, s1 = c[0] | (c[1] << 32), c[2] | (c[3] << 32)
+    a, b, cc, ctr = c[0] | (c[1] << 32), c[2] | (c[3] << 32), 0x9E3779B97F4A7C15, 1
     out = []
-    for _ in range(n):
-        r = (rotl((s0 + s1) & M, 17) + s0) & M
-        s1 ^= s0
-        s0, s1 = rotl(s0, 49) ^ s1 ^ ((s1 << 21) & M), rotl(s1, 28)
-        out.append((2 * (r >> 12) + 1) / 2.0 ** 53)
+    for i in range(n + 12):
+        t = (a + b + ctr) & M
+        ctr += 1
+        a = b ^ (b >> 11)
+        b = (cc + (cc << 3)) & M
+        cc = ((((cc << 24) | (cc >> 40)) & M) + t) & M
+        if i >= 12:
+            out.append((2 * (t >> 12) + 1) / 2.0 ** 53)
     return np.array(out)
+
+
+def test_sfc64_matches_numpy_bit_generator(orc):
+    # numpy.random.SFC64 is an independent implementation of the published generator: same state -> same outputs
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        a, b, c = (int(v) for v in rng.integers(0, 1 << 63, 3, dtype=np.uint64))
+        bg = np.random.SFC64()
+        st = bg.state
+        st["state"]["state"] = np.array([a, b, c, 1], dtype=np.uint64)
+        bg.state = st
+        assert orc.sfc64_raw(a, b, c, 1, 64) == [int(v) for v in bg.random_raw(64)]
 
 
 def test_stream_matches_big_integer_restatement(orc):

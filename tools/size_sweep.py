@@ -1,0 +1,47 @@
+"""Throughput of the filter against the number of particles (how much of k_propagate's time is ramp-up / tail).
+
+    python tools/size_sweep.py            # on the GPU box
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dpomp_amd as dp  # noqa: E402
+
+
+def main():
+    y = dp.get_observations(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "pooley.csv"))
+    model = dp.generate_model("SIS", [100, 1])
+    pf = dp.ParticleFilter(model, y)
+    rows = []
+    variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
+    theta = np.array([[0.003], [0.1]])
+    for lg in [int(v) for v in os.environ.get("LOG2P", "17,18,19,20,21,22").split(",")]:
+        P = 1 << lg
+        samples = {v: [] for v in variants}
+        ev = 0
+        for rep in range(7):            # variants interleaved, so clock drift hits them alike; median reported
+            for variant in variants:
+                pf.set_propagate_variant(variant)
+                pf.loglik(theta, P, seed=1)
+                t0 = time.perf_counter()
+                n = 3
+                for s in range(n):
+                    pf.loglik(theta, P, seed=2 + s)
+                samples[variant].append((time.perf_counter() - t0) / n)
+                ev = pf.last_event_count()
+        for variant in variants:
+            dt = float(np.median(samples[variant]))
+            rows.append({"variant": variant, "log2_P": lg, "ms": round(dt * 1e3, 4), "particle_steps_per_s": P * 5 / dt,
+                         "events_per_s": ev / dt, "spread_ms": round((max(samples[variant]) - min(samples[variant])) * 1e3, 4)})
+            print(json.dumps(rows[-1]), flush=True)
+        print(json.dumps({"log2_P": lg, "lane_utilisation": [round(float(u), 3) for u in pf.lane_utilisation()]}), flush=True)
+    pf.close()
+
+
+if __name__ == "__main__":
+    main()
