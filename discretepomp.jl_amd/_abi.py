@@ -104,6 +104,8 @@ _PROTOTYPES = {
     "dpomp_debug_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "dpomp_selftest_numerics": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_double),
                                           C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dpomp_selftest_division": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dpomp_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "dpomp_kernel_count": (C.c_int, []),
     "dpomp_kernel_name": (C.c_char_p, [C.c_int]),

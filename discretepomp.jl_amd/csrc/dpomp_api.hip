@@ -1142,6 +1142,23 @@ int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const dou
     return DPOMP_OK;
 }
 
+int dpomp_selftest_division(dpomp_handle* h, int64_t n, const double* a_in, const double* b_in, double* out_fast,
+                            double* out_plain) {
+    if (!h || !a_in || !b_in || !out_fast || !out_plain) return fail(h, DPOMP_EINVAL, "null argument");
+    if (n < 1) return fail(h, DPOMP_EINVAL, "n < 1");
+    HIPCHK(h, hipSetDevice(h->device));
+    double* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto& p : d) HIPCHK(h, hipMalloc((void**)&p, (size_t)n * 8));
+    HIPCHK(h, hipMemcpy(d[0], a_in, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d[1], b_in, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_selftest_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, d[0], d[1], d[2], d[3]);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(out_fast, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out_plain, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (auto& p : d) (void)hipFree(p);
+    return DPOMP_OK;
+}
+
 int dpomp_set_profiling(dpomp_handle* h, int on) {
     if (!h) return DPOMP_EINVAL;
     h->profiling = on != 0;

@@ -253,6 +253,48 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
     return v;
 }
 
+// ---- one Gillespie event --------------------------------------------------------------------------------
+// The body of iterate_particles! (hmm_particle_filter.jl:14-31): rates -> cumsum -> total == 0 ? -> time -= log(u)/total
+// -> time > tmax ? -> event by inverse CDF (strict >, last event falls through; hmm_cmn.jl:4-10) -> state +=
+// transition row -> event cap.  Returns true while the particle goes on.  FAST = the division may skip its range
+// handling (dpomp_numerics.h: div_in_range); a total outside that range -- zero included, i.e. an extinct epidemic --
+// stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
+// arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
+// stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
+template <class R, bool FAST>
+__device__ __forceinline__ bool gillespie_event(const DevModel& m, const double* thr, int (&x)[R::S], double& time,
+                                                const double tmax, Stream& rng, int& n, const int cap, const int e_real,
+                                                const double (*s_log)[2]) {
+    constexpr int S = R::S, E = R::E;
+    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
+    double cum[E];
+    R::rates(m, thr, x, cum);
+#pragma unroll
+    for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
+    const double tot = cum[E - 1];
+    if (FAST) {
+        if (!rate_in_fast_range(tot)) return false;
+    } else {
+        if (tot == 0.0) return false;
+    }
+    const double lu = dlog_tab(u01(stream_next(rng)), s_log);
+    time = time - (FAST ? div_in_range(lu, tot) : lu / tot);
+    if (time > tmax) return false;
+    const double etc = u01(stream_next(rng)) * tot;
+    TW tw = (TW)m.trans_packed[e_real - 1];
+#pragma unroll
+    for (int i = E - 2; i >= 0; --i) {
+        const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+        if (in_range && cum[i] > etc) tw = (TW)m.trans_packed[i];
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+    return ++n < cap;
+}
+__device__ __forceinline__ bool stopped_on_cap(int n, int cap) { return n >= cap; }
+// after a FAST loop returned false: neither the cap nor the clock stopped the particle, so its rate total did
+__device__ __forceinline__ bool stopped_on_range(int n, int cap, double time, double tmax) { return n < cap && !(time > tmax); }
+
 // ---- k_init: pop[i,:] .= initial_condition   (hmm_particle_filter.jl:42-44) -----------------
 __global__ __launch_bounds__(kBlock) void k_init(DevModel m, int32_t* state, int64_t Pp) {
     const int64_t b = blockIdx.y;
@@ -283,8 +325,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     const ThetaRegs<R> th_regs(th, a.m.K);
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
-    __shared__ double s_log[128][2];  // dlog table: one ds_read_b128 per event
-    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    __shared__ double s_log[kLogTableSize][2];  // dlog table: one ds_read_b128 per event
+    for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
     __syncthreads();
 
     int x[S];
@@ -300,30 +342,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     bool capped = false;
 
     if (valid) {
-        for (;;) {
-            double cum[E];
-            R::rates(a.m, thr, x, cum);
-#pragma unroll
-            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
-            const double tot = cum[E - 1];
-            if (tot == 0.0) break;
-            const double u1 = u01(stream_next(rng));
-            time = time - dlog_tab(u1, s_log) / tot;
-            if (time > tmax) break;
-            const double etc = u01(stream_next(rng)) * tot;
-            TW tw = (TW)a.m.trans_packed[e_real - 1];
-#pragma unroll
-            for (int i = E - 2; i >= 0; --i) {
-                const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
-            }
-#pragma unroll
-            for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-            if (++n >= cap) {
-                capped = true;
-                break;
-            }
-        }
+        while (gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+        if (stopped_on_range(n, cap, time, tmax))
+            while (gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+        capped = stopped_on_cap(n, cap);
     }
 
     double g = -__builtin_inf();
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     constexpr int S = R::S, E = R::E;
     constexpr int C = kBlock * RPL;
     using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
-    __shared__ double s_log[128][2];
+    __shared__ double s_log[kLogTableSize][2];
     __shared__ int32_t s_x[S][C];
     __shared__ uint4 s_seed[C];
     __shared__ int32_t s_cnt[C];  // executed events, bit 31 = hit the event cap
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     const ThetaRegs<R> th_regs(th, a.m.K);
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
-    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 #pragma unroll
     for (int jj = 0; jj < RPL; ++jj) {
         const int idx = jj * kBlock + threadIdx.x;
@@ -552,7 +574,7 @@ template <class R, int CHK>
 __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     constexpr int S = R::S, E = R::E;
     using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
-    __shared__ double s_log[128][2];
+    __shared__ double s_log[kLogTableSize][2];
     __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
     __shared__ int32_t s_cnt[kBlock];     // executed events, bit 31 = event cap
     // Compaction staging.  A compaction frees at least one wave, so at most kBlock - 64 contexts move; they go
@@ -581,7 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     const ThetaRegs<R> th_regs(th, a.m.K);
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
-    for (int i = threadIdx.x; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 
     int x[S];
 #pragma unroll
@@ -600,38 +622,15 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     for (int round = 0;; ++round) {
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             int it = 0;
-            for (;;) {
-                double cum[E];
-                R::rates(a.m, thr, x, cum);
-#pragma unroll
-                for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
-                const double tot = cum[E - 1];
-                if (tot == 0.0) {
-                    active = false;
-                    break;
-                }
-                const double u1 = u01(stream_next(rng));
-                time = time - dlog_tab(u1, s_log) / tot;
-                if (time > tmax) {
-                    active = false;
-                    break;
-                }
-                const double etc = u01(stream_next(rng)) * tot;
-                TW tw = (TW)a.m.trans_packed[e_real - 1];
-#pragma unroll
-                for (int i = E - 2; i >= 0; --i) {
-                    const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                    if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-                if (++n >= cap) {
-                    capped = true;
-                    active = false;
-                    break;
-                }
-                if (++it >= CHK) break;
+            bool go;
+            do go = gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+            while (go && ++it < CHK);
+            if (!go && stopped_on_range(n, cap, time, tmax)) {
+                do go = gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+                while (go && ++it < CHK);
             }
+            active = go;
+            capped = stopped_on_cap(n, cap);
         }
         if (!active && !parked) {  // once per particle, outside the hot loop
 #pragma unroll
@@ -771,7 +770,7 @@ template <class R>
 __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     constexpr int S = R::S, E = R::E;
     using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
-    __shared__ double s_log[128][2];
+    __shared__ double s_log[kLogTableSize][2];
     __shared__ int32_t s_x[S][kBlock];
     __shared__ int32_t s_N[kBlock];
     __shared__ double s_wmax[kBlock / 64];
@@ -787,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     const double* th = a.theta + (int64_t)b * a.m.K;
     const ThetaRegs<R> th_regs(th, a.m.K);
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
-    for (int i = tid; i < 256; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    for (int i = tid; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
 
     int x[S];
 #pragma unroll
@@ -810,29 +809,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         int n = 0;
         bool capped = false;
         if (valid) {
-            for (;;) {
-                double cum[E];
-                R::rates(a.m, thr, x, cum);
-#pragma unroll
-                for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
-                const double tot = cum[E - 1];
-                if (tot == 0.0) break;
-                time = time - dlog_tab(u01(stream_next(rng)), s_log) / tot;
-                if (time > tmax) break;
-                const double etc = u01(stream_next(rng)) * tot;
-                TW tw = (TW)a.m.trans_packed[e_real - 1];
-#pragma unroll
-                for (int i = E - 2; i >= 0; --i) {
-                    const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                    if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-                if (++n >= cap) {
-                    capped = true;
-                    break;
-                }
-            }
+            while (gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            if (stopped_on_range(n, cap, time, tmax))
+                while (gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            capped = stopped_on_cap(n, cap);
         }
         ev += (unsigned long long)n;
         any_cap |= capped;
@@ -1399,6 +1379,14 @@ __global__ void k_selftest(int64_t n, uint64_t seed, const double* x, double* ou
     }
     if (x && out_log) out_log[i] = dlog(x[i]);
     if (x && out_exp) out_exp[i] = dexp(-37.0 * x[i]);
+}
+
+// Device quotients a[i] / b[i] by the event loop's in-range division (b in its range) and by the plain `/`.
+__global__ void k_selftest_div(int64_t n, const double* a, const double* b, double* out_fast, double* out_plain) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_fast[i] = rate_in_fast_range(b[i]) ? div_in_range(a[i], b[i]) : __builtin_nan("");
+    out_plain[i] = a[i] / b[i];
 }
 
 }  // namespace dpomp

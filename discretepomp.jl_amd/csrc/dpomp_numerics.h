@@ -149,13 +149,15 @@ DPOMP_HD double u01(uint64_t x) {
 }
 
 // log(x), positive normal x, table-driven and division-free (the structure of glibc's log):
-//   bits(x) - OFF splits x = 2^k z with z in [0.6875, 1.375); subinterval i = next 7 bits;
+//   bits(x) - OFF splits x = 2^k z with z in [0.6875, 1.375); subinterval i = next 9 bits;
 //   T[i] = (invc, logc) with invc = RN(1/c_i), logc = RN(-log(invc))  (tools/gen_log_table.py);
-//   r = fma(z, invc, -1)  (|r| <= 2^-7),  log(x) = k ln2 + logc + log1p(r),
-//   log1p(r) = r + r^2 (A0 + A1 r + ... + A6 r^6),  A_n = (-1)^(n+1)/(n+2).
+//   r = fma(z, invc, -1)  (|r| <= 2^-9.5),  log(x) = (k ln2hi + logc) + (k ln2lo + log1p(r)),
+//   log1p(r) = r + r^2 (A0 + A1 r + ... + A4 r^4),  A_n = (-1)^(n+1)/(n+2).
 // The two subintervals touching 1 have c = 1 (invc = 1, logc = 0), so log(x) keeps full relative
-// accuracy as x -> 1.  Max error 1 ulp (tests/test_oracle_numerics.py).  In k_propagate the
-// table lives in LDS (one ds_read_b128 per event).
+// accuracy as x -> 1.  Max error 1.5 ulp (tests/test_oracle_numerics.py).  17 VALU instructions on gfx950;
+// the first version (128 entries, terms to r^8, compensated sum: 1.3 ulp) took 24.  In k_propagate the
+// 8 KB table lives in LDS (one ds_read_b128 per event).
+constexpr int kLogTableSize = 512;
 // On the device the polynomial constants are pinned to scalar registers: a wave-uniform fma addend then comes
 // straight from an SGPR pair, where the compiler otherwise parks the literals in VGPRs and spends a v_mov_b64 per
 // Horner step re-materialising the accumulator.
@@ -170,25 +172,55 @@ inline double scalar_const(double v) { return v; }
 
 DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
     const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
-    const double A0 = -0.5, A1 = scalar_const(0x1.5555555555555p-2), A2 = -0.25, A3 = scalar_const(0x1.999999999999ap-3),
-                 A4 = scalar_const(-0x1.5555555555555p-3), A5 = scalar_const(0x1.2492492492492p-3), A6 = -0.125;
+    const double A0 = -0.5, A1 = scalar_const(0x1.5555555555555p-2), A2 = scalar_const(-0.25),
+                 A3 = scalar_const(0x1.999999999999ap-3), A4 = -0x1.5555555555555p-3;
+    // only the high word of bits(x) takes part in the range reduction (OFF and the exponent mask have a zero low word)
     const uint64_t ix = double_to_bits(x);
-    const uint64_t tmp = ix - 0x3FE6000000000000ull;
-    const int i = (int)((uint32_t)(tmp >> 45) & 127u);
-    const int32_t k = (int32_t)(uint32_t)(tmp >> 32) >> 20;  // arithmetic shift of the high word == (int64)tmp >> 52
-    const double z = bits_to_double(ix - (tmp & 0xFFF0000000000000ull));
+    const uint32_t hx = (uint32_t)(ix >> 32);
+    const uint32_t tmp = hx - 0x3FE60000u;
+    const int i = (int)((tmp >> 11) & 511u);
+    const int32_t k = (int32_t)tmp >> 20;
+    const double z = bits_to_double(((uint64_t)(hx - (tmp & 0xFFF00000u)) << 32) | (uint32_t)ix);
     const double invc = T[i][0], logc = T[i][1];
     const double r = __builtin_fma(z, invc, -1.0);
     const double kd = (double)k;
     const double w = __builtin_fma(kd, Ln2hi, logc);
-    const double hi = w + r;
-    const double lo = __builtin_fma(kd, Ln2lo, (w - hi) + r);
+    const double s = __builtin_fma(kd, Ln2lo, r);
     const double r2 = r * r;
-    const double p = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r,
-                     __builtin_fma(r, __builtin_fma(r, A6, A5), A4), A3), A2), A1), A0);
-    return __builtin_fma(r2, p, lo) + hi;
+    const double p = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, A4, A3), A2), A1), A0);
+    return w + __builtin_fma(r2, p, s);
 }
 DPOMP_D double dlog(double x) { return dlog_tab(x, kLogTable); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Waiting time log(u) / total with the IEEE quotient but without the range machinery of the compiler's division.
+// The compiler expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps, q0 = a y, r = a - b q0,
+// v_div_fmas (q0 + r y) and v_div_fixup; the scale / fmas / fixup instructions only act when an operand or the
+// quotient is zero, subnormal, infinite, NaN or needs pre-scaling against overflow.  For 2^-200 <= b <= 2^200 and
+// 2^-60 <= |a| <= 2^60 they are identities, and the remaining eight instructions are the same Newton-Markstein
+// sequence, so the result is the correctly rounded quotient -- what `/` gives on the host (checked against `/` by
+// dpomp_selftest_numerics and, implicitly, by every parity test).  |log(u)| is in [2^-53, 37] by construction;
+// the rate total is tested (one integer compare on its high word) and anything else -- a zero total, i.e. a
+// particle that can no longer move, included -- leaves the fast event loop for one with the plain division.
+__device__ __forceinline__ bool rate_in_fast_range(double total) {
+    return (uint32_t)(__double2hiint(total) - 0x33700000) < 0x19000000u;  // 2^-200 <= total < 2^200, positive, finite
+}
+__device__ __forceinline__ double div_in_range(double a, double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double r = __builtin_fma(-b, q, a);
+    return __builtin_fma(r, y, q);
+}
+#else  // host pass of the HIP compilation and the host twin library: same predicate, the plain quotient
+DPOMP_HD bool rate_in_fast_range(double total) {
+    return (uint32_t)((uint32_t)(double_to_bits(total) >> 32) - 0x33700000u) < 0x19000000u;
+}
+DPOMP_HD double div_in_range(double a, double b) { return a / b; }
+#endif
 
 // exp(x), -37 <= x <= 0.
 DPOMP_HD double dexp(double x) {

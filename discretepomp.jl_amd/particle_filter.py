@@ -274,6 +274,14 @@ class ParticleFilter:
         self._check(self._lib.dpomp_selftest_numerics(self._h, n, int(seed), _dptr(x), _dptr(u), _dptr(lg), _dptr(ex)))
         return u, lg, ex
 
+    def selftest_division(self, a: np.ndarray, b: np.ndarray):
+        """Device quotients a / b: (event loop's in-range division, plain division)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        fast, plain = np.empty(a.shape[0]), np.empty(a.shape[0])
+        self._check(self._lib.dpomp_selftest_division(self._h, a.shape[0], _dptr(a), _dptr(b), _dptr(fast), _dptr(plain)))
+        return fast, plain
+
 
 def check_rate_source(model: DPOMPModel, obs_data: Sequence[Observation]) -> str:
     """Compile-only check of a :class:`RateSource` model (needs no GPU).  Returns the compiler log; raises

@@ -241,6 +241,11 @@ int dpomp_debug_download(dpomp_handle* h, const dpomp_pop* pop, int what, int64_
 int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const double* x_in,
                             double* out_uniform, double* out_log, double* out_exp);
 
+/* Test hook: device quotients a[i] / b[i] by the event loop's range-checked fast division (NaN where b[i] is outside
+ * its range, 2^-200 <= b < 2^200) and by the plain device division; both must equal the host's IEEE quotient. */
+int dpomp_selftest_division(dpomp_handle* h, int64_t n, const double* a_in, const double* b_in, double* out_fast,
+                            double* out_plain);
+
 /* Per-kernel HIP-event timing, accumulated while profiling is on. */
 int dpomp_set_profiling(dpomp_handle* h, int on);
 int dpomp_kernel_count(void);

@@ -121,16 +121,16 @@ void orc_uniforms(uint64_t seed, uint32_t b, uint32_t p, uint32_t k, uint32_t do
 
 /* log(x) for positive normal x, table-driven (structure of glibc's log; table generated by
  * tools/gen_log_table.py, re-derived entry by entry in tests/test_oracle_numerics.py):
- * x = 2^k z, z in [0.6875, 1.375); T[i] = (invc, logc) for the i-th of 128 subintervals;
- * r = fma(z, invc, -1); log(x) = k ln2 + logc + r + r^2 (A0 + ... + A6 r^6).  Max error 1 ulp. */
+ * x = 2^k z, z in [0.6875, 1.375); T[i] = (invc, logc) for the i-th of 512 subintervals (|r| <= 2^-9.5);
+ * r = fma(z, invc, -1); log(x) = (k ln2hi + logc) + (k ln2lo + r + r^2 (A0 + ... + A4 r^4)).  Max error 1.5 ulp. */
 double orc_dlog(double x) {
     static const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
     static const double A0 = -0.5, A1 = 0x1.5555555555555p-2, A2 = -0.25, A3 = 0x1.999999999999ap-3,
-                        A4 = -0x1.5555555555555p-3, A5 = 0x1.2492492492492p-3, A6 = -0.125;
+                        A4 = -0x1.5555555555555p-3;
     uint64_t ix;
     memcpy(&ix, &x, 8);
     uint64_t tmp = ix - 0x3FE6000000000000ull;
-    int i = (int)((tmp >> 45) & 127);
+    int i = (int)((tmp >> 43) & 511);
     int32_t k = (int32_t)((int64_t)tmp >> 52);
     uint64_t iz = ix - (tmp & 0xFFF0000000000000ull);
     double z;
@@ -139,11 +139,10 @@ double orc_dlog(double x) {
     double r = fma(z, invc, -1.0);
     double kd = (double)k;
     double w = fma(kd, Ln2hi, logc);
-    double hi = w + r;
-    double lo = fma(kd, Ln2lo, (w - hi) + r);
+    double s = fma(kd, Ln2lo, r);
     double r2 = r * r;
-    double p = fma(r, fma(r, fma(r, fma(r, fma(r, fma(r, A6, A5), A4), A3), A2), A1), A0);
-    return fma(r2, p, lo) + hi;
+    double p = fma(r, fma(r, fma(r, fma(r, A4, A3), A2), A1), A0);
+    return w + fma(r2, p, s);
 }
 
 /* exp(x) for -37 <= x <= 0 (callers cut off below -37, where the fixed-point weight

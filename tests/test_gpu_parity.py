@@ -551,3 +551,28 @@ def test_automatic_schedule_switches_per_interval_and_keeps_results(dp, pooley):
     assert a[0] == b[0] == c[0]
     assert np.array_equal(pf.lane_utilisation(), u)
     pf.close()
+
+
+def test_event_loop_division_is_the_ieee_quotient(sis):
+    """The event loop divides log(u) by the rate total with the compiler's Newton-Markstein sequence minus its range
+    handling (dpomp_numerics.h: div_in_range).  Inside its range it must return the correctly rounded quotient --
+    numpy's -- for every operand pair, including totals at the edges of the range and quotients that are hard to
+    round; outside it reports itself out of range."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    u = (2 * rng.integers(0, 1 << 52, n, dtype=np.uint64) + 1).astype(np.float64) * 2.0 ** -53
+    a = np.log(u)                                            # numerators as the loop sees them: -37 .. -2^-53
+    b = np.exp(rng.uniform(np.log(1e-12), np.log(1e12), n))  # rate totals over 24 decades
+    b[: n // 8] = rng.integers(1, 1 << 20, n // 8) * 0.003   # and lattice-like totals (theta * S * I)
+    edge = np.array([2.0 ** -200, np.nextafter(2.0 ** 200, 0), 1.0, 3.0, 2.0 ** -199 * 1.5, 2.0 ** 199 * 1.999])
+    a = np.concatenate([a, [-1.0, -36.7, -2.0 ** -53, -1.0 / 3.0, -0.1, -1e-10]])
+    b = np.concatenate([b, edge])
+    fast, plain = sis.selftest_division(a, b)
+    assert np.array_equal(plain, a / b)
+    assert np.array_equal(fast, a / b)
+    out = np.array([0.0, -1.0, 2.0 ** -201, 2.0 ** 200, np.inf, np.nan, 5e-324])
+    fast, plain = sis.selftest_division(-np.ones(out.size), out)
+    assert np.all(np.isnan(fast))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = -1.0 / out
+    assert np.array_equal(plain, want, equal_nan=True)

@@ -76,7 +76,7 @@ def _max_ulp(vals, refs):
     return worst
 
 
-def test_dlog_within_one_and_a_half_ulp(orc):
+def test_dlog_within_one_and_a_half_ulp(orc):  # measured 1.43
     mp.mp.prec = 200
     rng = np.random.default_rng(0)
     xs = np.concatenate([rng.random(8000), 1 - rng.random(2000) * 2.0 ** -7, 1 + rng.random(1000) * 2.0 ** -7,
@@ -95,8 +95,8 @@ def test_log_table_entries_rederived():
     OFF = 0x3FE6000000000000
     val = lambda b: mp.mpf(struct.unpack("<d", struct.pack("<Q", b))[0])
     want = []
-    for i in range(128):
-        lo, hi = val(OFF + (i << 45)), val(OFF + ((i + 1) << 45))
+    for i in range(512):
+        lo, hi = val(OFF + (i << 43)), val(OFF + ((i + 1) << 43))
         if lo == 1 or hi == 1:
             want.append((1.0, 0.0))
         else:
