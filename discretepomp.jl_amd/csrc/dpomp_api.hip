@@ -33,10 +33,13 @@ typedef void (*PropFn)(PropArgs);
 
 constexpr int64_t kCompactionMinWaves = 8192;
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
-// Automatic schedule: an interval runs with workgroup compaction when, the last time this handle ran it, a
-// one-particle-per-lane schedule kept fewer than this fraction of the lanes busy (the kernels report that figure
-// whichever schedule they ran).  Compaction costs ~6 % when lanes finish together and saves 20-30 % when they do not.
-constexpr double kCompactionBelowUtil = 0.70;
+// Automatic schedule, per observation interval.  A launch that fills the chip (>= 8192 waves: the issue slots a
+// compaction frees are taken by other waves) runs with workgroup compaction unless, the last time this handle ran the
+// interval, a one-particle-per-lane schedule kept at least this fraction of the lanes busy (the kernels report that
+// figure whichever schedule they ran).  Measured on MI355X (tools/size_sweep.py): compaction wins by 1-4 % at
+// utilisations of 0.75-0.87 and by 20-30 % where epidemics die out early (0.3); below 8192 waves the static kernel
+// wins by 2-7 %.
+constexpr double kCompactionBelowUtil = 0.90;
 constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 
@@ -470,8 +473,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             // taken by other waves); below that the plain kernel wins by 10-15 % (tools/latency_probe.py).
             int rpl = h->force_rpl;
             if (rpl == 0)
-                rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] >= 0.0 &&
-                       h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
+                rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil)
+                          ? kDefaultPropVariant : 1;  // lane_util = -1 (not measured yet) -> compaction
             if (h->rtc && rpl != 32) rpl = 1;  // run-time compiled models come in two variants
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56

@@ -261,12 +261,34 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
 // stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
 // arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
 // stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
+// The packed transition rows, held in VGPRs for the whole event loop: selecting between two SGPR operands costs two
+// v_mov per event on top of the v_cndmask (one constant-bus read per VALU instruction on gfx9).  v[E-1] is the row
+// of the last real event (the inverse-CDF search falls through to it).
+template <class R>
+struct TransRows {
+    using TW = typename cond_t<(R::S <= 4), uint32_t, uint64_t>::type;
+    TW v[R::E];
+    __device__ __forceinline__ TransRows(const DevModel& m, int e_real) {
+#pragma unroll
+        for (int i = 0; i < R::E; ++i) v[i] = (TW)m.trans_packed[i];
+        if (R::kGeneric) {  // padded evaluator: the last real row (selected with constant indices only)
+#pragma unroll
+            for (int i = 0; i < R::E - 1; ++i)
+                if (i == e_real - 1) v[R::E - 1] = (TW)m.trans_packed[i];
+        }
+        if (!R::kGeneric) {
+#pragma unroll
+            for (int i = 0; i < R::E; ++i) asm volatile("" : "+v"(v[i]));
+        }
+    }
+};
+
 template <class R, bool FAST>
-__device__ __forceinline__ bool gillespie_event(const DevModel& m, const double* thr, int (&x)[R::S], double& time,
-                                                const double tmax, Stream& rng, int& n, const int cap, const int e_real,
-                                                const double (*s_log)[2]) {
+__device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRows<R> rows, const double* thr,
+                                                int (&x)[R::S], double& time, const double tmax, Stream& rng, int& n,
+                                                const int cap, const int e_real, const double (*s_log)[2]) {
     constexpr int S = R::S, E = R::E;
-    using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
+    using TW = typename TransRows<R>::TW;
     double cum[E];
     R::rates(m, thr, x, cum);
 #pragma unroll
@@ -281,11 +303,11 @@ __device__ __forceinline__ bool gillespie_event(const DevModel& m, const double*
     time = time - (FAST ? div_in_range(lu, tot) : lu / tot);
     if (time > tmax) return false;
     const double etc = u01(stream_next(rng)) * tot;
-    TW tw = (TW)m.trans_packed[e_real - 1];
+    TW tw = rows.v[E - 1];
 #pragma unroll
     for (int i = E - 2; i >= 0; --i) {
         const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-        if (in_range && cum[i] > etc) tw = (TW)m.trans_packed[i];
+        if (in_range && cum[i] > etc) tw = rows.v[i];
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
@@ -337,14 +359,15 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     const double tmax = a.t_max;
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
     const int e_real = R::kGeneric ? a.m.E : E;
+    const TransRows<R> rows(a.m, e_real);
     const int cap = a.m.cap;
     int n = 0;
     bool capped = false;
 
     if (valid) {
-        while (gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+        while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
         if (stopped_on_range(n, cap, time, tmax))
-            while (gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
         capped = stopped_on_cap(n, cap);
     }
 
@@ -449,6 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     const double t_start = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
     const int e_real = R::kGeneric ? a.m.E : E;
+    const TransRows<R> rows(a.m, e_real);
     const int cap = a.m.cap;
     int x[S];
 #pragma unroll
@@ -612,6 +636,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     const double tmax = a.t_max;
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
     const int e_real = R::kGeneric ? a.m.E : E;
+    const TransRows<R> rows(a.m, e_real);
     const int cap = a.m.cap;
     int n = 0, cur = threadIdx.x;
     bool active = valid;  // particle still running
@@ -623,10 +648,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             int it = 0;
             bool go;
-            do go = gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
             while (go && ++it < CHK);
             if (!go && stopped_on_range(n, cap, time, tmax)) {
-                do go = gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
                 while (go && ++it < CHK);
             }
             active = go;
@@ -782,6 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     const bool valid = tid < a.P;
     const int s_real = R::kGeneric ? a.m.S : S;
     const int e_real = R::kGeneric ? a.m.E : E;
+    const TransRows<R> rows(a.m, e_real);
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
     const ThetaRegs<R> th_regs(th, a.m.K);
@@ -809,9 +835,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         int n = 0;
         bool capped = false;
         if (valid) {
-            while (gillespie_event<R, true>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
             if (stopped_on_range(n, cap, time, tmax))
-                while (gillespie_event<R, false>(a.m, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+                while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
             capped = stopped_on_cap(n, cap);
         }
         ev += (unsigned long long)n;
@@ -912,6 +938,7 @@ __global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
     if (p >= a.P) return;
     const int s_real = R::kGeneric ? a.m.S : S;
     const int e_real = R::kGeneric ? a.m.E : E;
+    const TransRows<R> rows(a.m, e_real);
     int x[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] = (s < s_real) ? a.m.x0[s] : 0;

@@ -177,9 +177,9 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type);
  * observation (increment = LSE(carried + new) - LSE(carried)).  The carry state lives in the population handle. */
 int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac);
 
-/* Tuning: variant of the propagation kernel.  0 = library default (per observation interval: one
- * particle per lane, or workgroup compaction when the previous call measured a lane utilisation below 0.7 for that
- * interval on a chip-filling launch, see dpomp_get_lane_utilisation); 1 = one particle per lane; 2, 4 =
+/* Tuning: variant of the propagation kernel.  0 = library default (per observation interval: workgroup
+ * compaction on a chip-filling launch unless the previous call measured a lane utilisation of 0.9 or more for that
+ * interval, one particle per lane otherwise; see dpomp_get_lane_utilisation); 1 = one particle per lane; 2, 4 =
  * workgroup-local LDS queue with that many particles per lane and dynamic lane refill; 16, 32 = one particle per
  * lane with workgroup-level compaction every that many events.  Results do not depend on it. */
 int dpomp_set_propagate_variant(dpomp_handle* h, int variant);

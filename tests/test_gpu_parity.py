@@ -535,17 +535,17 @@ def test_lane_utilisation_statistic_matches_oracle_event_counts(sis, orc, rpl):
     sis.set_propagate_variant(0)
 
 
-def test_automatic_schedule_switches_per_interval_and_keeps_results(dp, pooley):
-    """Chip-filling launch (2^19 particles = 8192 waves): the first call runs one particle per lane everywhere and
-    measures the lane utilisation; the second call uses compaction where it was below 0.7 (Pooley: the first
-    interval, where most epidemics die out at once).  Results do not depend on the schedule."""
+def test_automatic_schedule_reads_lane_utilisation_and_keeps_results(dp, pooley):
+    """Chip-filling launch (2^19 particles = 8192 waves): the automatic schedule runs compaction unless the interval
+    measured a lane utilisation >= 0.9 last time.  Pooley: 0.30 in the first interval (most epidemics die out at
+    once), 0.82-0.87 afterwards.  Results do not depend on the schedule."""
     pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
     theta = np.array([[0.003], [0.1]])
     assert np.all(pf.lane_utilisation() == -1.0)
     a = pf.loglik(theta, 1 << 19, seed=21)
     u = pf.lane_utilisation()
-    assert u[0] < 0.7 and np.all(u[1:] > 0.7), u
-    b = pf.loglik(theta, 1 << 19, seed=21)          # now with compaction in interval 1
+    assert u[0] < 0.4 and np.all(u[1:] > 0.75) and np.all(u[1:] < 0.9), u
+    b = pf.loglik(theta, 1 << 19, seed=21)
     pf.set_propagate_variant(1)
     c = pf.loglik(theta, 1 << 19, seed=21)
     assert a[0] == b[0] == c[0]
