@@ -82,6 +82,7 @@ def cpu_baseline(dp, P_serial, P_parallel):
     rp = orc.pf_loglik(desc, P_parallel, THETA, seed=1, nthreads=cores)
     t_par = time.perf_counter() - t0
     return {
+        "ll": rp.ll,
         "value": P_parallel * T / t_par,
         "unit": "particle-steps/s",
         "cores": cores,
@@ -104,8 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", type=int, default=1 << 20)
-    ap.add_argument("--cpu-serial-particles", type=int, default=1 << 16)
-    ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 19)
+    ap.add_argument("--cpu-serial-particles", type=int, default=1 << 17)
+    ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
     args = ap.parse_args()
@@ -244,14 +245,14 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as orc
-            # log-ML abs error vs the CPU reference path at identical seed (bit parity expected)
-            Pc = 1 << 16
-            gpu_ll = float(pf.loglik(THETA, Pc, seed=7)[0])
-            cpu_ll = orc.pf_loglik(pf.desc, Pc, THETA, seed=7, nthreads=max(1, os.cpu_count() or 1)).ll
+            # log-ML abs error vs the CPU path at identical seed, on the CPU baseline's own run (by default the whole
+            # 2^20-particle workload): bit parity expected
+            result["cpu_baseline"] = cpu_baseline(dp, args.cpu_serial_particles, args.cpu_parallel_particles)
+            Pc = args.cpu_parallel_particles
+            gpu_ll = float(pf.loglik(THETA, Pc, seed=1)[0])
+            cpu_ll = result["cpu_baseline"].pop("ll")
             result["log_ml"]["abs_err_vs_cpu_same_seed"] = abs(gpu_ll - cpu_ll)
             result["log_ml"]["same_seed_particles"] = Pc
-            result["cpu_baseline"] = cpu_baseline(dp, args.cpu_serial_particles, args.cpu_parallel_particles)
             result["speedup_vs_cpu_allcores"] = result["value"] / result["cpu_baseline"]["value"]
             result["speedup_vs_cpu_serial"] = result["value"] / result["cpu_baseline"]["serial_value"]
         print(json.dumps(result))

@@ -225,6 +225,15 @@ struct ScopedTiming {
     }
 };
 
+// Resolving a bracket costs a host call per kernel; doing it at the end of every filter call would leave the GPU idle
+// meanwhile, so brackets pile up (the calls are synchronous: their events have completed) and are resolved when the
+// statistics are read, profiling is switched off, or the pile gets large.
+constexpr size_t kMaxPendingBrackets = 8192;
+void collect_timings(dpomp_handle* h);
+void collect_timings_if_many(dpomp_handle* h) {
+    if (h->pending.size() >= kMaxPendingBrackets) collect_timings(h);
+}
+
 void collect_timings(dpomp_handle* h) {
     for (const PendingTiming& p : h->pending) {
         float ms = 0.f;
@@ -427,7 +436,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         std::vector<char> result(p->ctl_result_bytes);
         HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
-        collect_timings(h);
+        collect_timings_if_many(h);
         if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
         memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
         if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
@@ -575,7 +584,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     std::vector<char> result(p->ctl_result_bytes);
     HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    collect_timings(h);
+    collect_timings_if_many(h);
     if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
     memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
     if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
@@ -950,7 +959,7 @@ int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
     p->cur ^= 1;
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    collect_timings(h);
+    collect_timings_if_many(h);
     return DPOMP_OK;
 }
 
@@ -974,7 +983,7 @@ int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const 
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    collect_timings(h);
+    collect_timings_if_many(h);
     dst->initialised = true;
     return DPOMP_OK;
 }
@@ -1164,6 +1173,10 @@ int dpomp_selftest_division(dpomp_handle* h, int64_t n, const double* a_in, cons
 
 int dpomp_set_profiling(dpomp_handle* h, int on) {
     if (!h) return DPOMP_EINVAL;
+    if (!on && !h->pending.empty()) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        collect_timings(h);
+    }
     h->profiling = on != 0;
     if (on && h->null_bracket_ms == 0.0) {  // calibrate the bracket itself once
         HIPCHK(h, hipSetDevice(h->device));
@@ -1208,6 +1221,10 @@ const char* dpomp_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? 
 
 int dpomp_get_kernel_stat(dpomp_handle* h, int kid, int64_t* launches, double* total_ms) {
     if (!h || kid < 0 || kid >= KID_COUNT) return DPOMP_EINVAL;
+    if (!h->pending.empty()) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        collect_timings(h);
+    }
     if (launches) *launches = h->stats[kid].launches;
     if (total_ms) *total_ms = h->stats[kid].total_ms;
     return DPOMP_OK;
