@@ -340,7 +340,9 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     // result download per call
     {
         const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
-        const size_t n_sc = (size_t)p->T * 16;  // per observation: events, 64 * sum of per-wave maxima
+        // per observation: executed events and 64 * sum of per-wave maxima, each counter in a 128-byte line of its own
+        // (two atomics of one workgroup on the same line cost ~9 ns each at the L2; on separate lines they are free)
+        const size_t n_sc = (size_t)p->T * kSchedStride * 8;
         p->sched_offset = n_ll + n_ev + n_st;
         p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
         p->ctl_bytes = p->ctl_result_bytes + n_sm;
@@ -475,7 +477,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
         a.yval = h->d_obs_val + (size_t)k * h->n_obs_values;
         a.n_yval = h->n_obs_values;
-        a.sched = reinterpret_cast<unsigned long long*>(p->ctl + p->sched_offset) + 2 * (size_t)k;
+        a.sched = reinterpret_cast<unsigned long long*>(p->ctl + p->sched_offset) + kSchedStride * (size_t)k;
         {
             // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
             // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
@@ -588,10 +590,13 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
     memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
     if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
-    if (domain == DOMAIN_PROPAGATE) {
+    {
         const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(result.data() + p->sched_offset);
-        for (int k = ymin - 1; k < ymax; ++k)
-            if (sc[2 * k + 1]) h->lane_util[k] = (double)sc[2 * k] / (double)sc[2 * k + 1];
+        for (int k = ymin - 1; k < ymax; ++k) {
+            const unsigned long long ev = sc[kSchedStride * k], slots = sc[kSchedStride * k + kSchedSlots];
+            h->last_events += ev;  // the propagate kernels count events per interval
+            if (slots && domain == DOMAIN_PROPAGATE) h->lane_util[k] = (double)ev / (double)slots;
+        }
     }
     return DPOMP_OK;
 }

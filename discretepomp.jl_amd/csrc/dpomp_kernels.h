@@ -69,8 +69,10 @@ struct PropArgs {
     const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
     const long long* yval;    // [V] Observation.val of this observation (user observation models)
     int32_t n_yval;
-    unsigned long long* sched;  // [2] or null: += sum of per-particle events, += sum over waves of 64 * (max events in wave)
+    unsigned long long* sched;  // this interval's counters: [0] += executed events, [kSchedSlots] += sum over waves of 64 * (max events in wave)
 };
+constexpr int kSchedSlots = 16;   // u64 index of the second counter: 128 bytes after the first, i.e. another L2 line
+constexpr int kSchedStride = 32;  // u64 per observation interval
 
 // ---- rate evaluators (the pluggable part) -------------------------------------------------
 // Each evaluator restates one reference rate function with the same association order:
@@ -412,11 +414,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
             bc |= s_cap[w];
         }
         if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
-        if (be) atomicAdd(a.events, be);
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
-        if (a.sched && be) {  // what a one-particle-per-lane schedule makes of this interval (dpomp_get_lane_utilisation)
+        if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
             atomicAdd(&a.sched[0], be);
-            atomicAdd(&a.sched[1], 64ull * bs);
+            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
         }
     }
 }
@@ -754,11 +755,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
             bc |= s_cap[w];
         }
         if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
-        if (be) atomicAdd(a.events, be);
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
-        if (a.sched && be) {
+        if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
             atomicAdd(&a.sched[0], be);
-            atomicAdd(&a.sched[1], 64ull * bs);
+            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
         }
     }
 }
