@@ -255,14 +255,6 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
     return v;
 }
 
-// ---- one Gillespie event --------------------------------------------------------------------------------
-// The body of iterate_particles! (hmm_particle_filter.jl:14-31): rates -> cumsum -> total == 0 ? -> time -= log(u)/total
-// -> time > tmax ? -> event by inverse CDF (strict >, last event falls through; hmm_cmn.jl:4-10) -> state +=
-// transition row -> event cap.  Returns true while the particle goes on.  FAST = the division may skip its range
-// handling (dpomp_numerics.h: div_in_range); a total outside that range -- zero included, i.e. an extinct epidemic --
-// stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
-// arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
-// stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
 // The packed transition rows, held in VGPRs for the whole event loop: selecting between two SGPR operands costs two
 // v_mov per event on top of the v_cndmask (one constant-bus read per VALU instruction on gfx9).  v[E-1] is the row
 // of the last real event (the inverse-CDF search falls through to it).
@@ -285,6 +277,14 @@ struct TransRows {
     }
 };
 
+// ---- one Gillespie event --------------------------------------------------------------------------------
+// The body of iterate_particles! (hmm_particle_filter.jl:14-31): rates -> cumsum -> total == 0 ? -> time -= log(u)/total
+// -> time > tmax ? -> event by inverse CDF (strict >, last event falls through; hmm_cmn.jl:4-10) -> state +=
+// transition row -> event cap.  Returns true while the particle goes on.  FAST = the division may skip its range
+// handling (dpomp_numerics.h: div_in_range); a total outside that range -- zero included, i.e. an extinct epidemic --
+// stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
+// arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
+// stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
 template <class R, bool FAST>
 __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRows<R> rows, const double* thr,
                                                 int (&x)[R::S], double& time, const double tmax, Stream& rng, int& n,
