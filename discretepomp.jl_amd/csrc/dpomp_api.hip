@@ -164,6 +164,8 @@ struct dpomp_pop {
     int carry_cur = 0;
     char* ctl = nullptr;                   // control block, see pop_alloc_impl
     size_t ctl_bytes = 0, ctl_result_bytes = 0, sched_offset = 0;
+    char* h_result = nullptr;    // pinned host staging: result download and parameter upload of a call are true
+    double* h_theta = nullptr;   // asynchronous copies (pageable memory makes each a blocking, staged transfer)
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]      (inside ctl)
@@ -304,6 +306,8 @@ void pop_release(dpomp_pop* p) {
     (void)hipFree(p->wtot);
     (void)hipFree(p->theta);
     (void)hipFree(p->ancestors);
+    (void)hipHostFree(p->h_result);
+    (void)hipHostFree(p->h_theta);
     delete p;
 }
 
@@ -356,6 +360,11 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->theta, (size_t)B * p->K * 8);
     DPOMP_ALLOC(p->ancestors, (size_t)B * 8);
 #undef DPOMP_ALLOC
+    if (hipHostMalloc((void**)&p->h_result, p->ctl_result_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&p->h_theta, (size_t)B * p->K * 8, hipHostMallocDefault) != hipSuccess) {
+        pop_release(p);
+        return fail(h, DPOMP_ENOMEM, "hipHostMalloc of the staging buffers failed");
+    }
     *out = p;
     return DPOMP_OK;
 }
@@ -395,7 +404,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         HIPCHK(h, hipMalloc((void**)&p->noresample, (size_t)B * 4));
     }
     if (adaptive && ymin == 1) HIPCHK(h, hipMemsetAsync(p->carry[p->carry_cur], 0, (size_t)B * 4, st));
-    HIPCHK(h, hipMemcpyAsync(p->theta, theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
+    memcpy(p->h_theta, theta, (size_t)B * p->K * 8);
+    HIPCHK(h, hipMemcpyAsync(p->theta, p->h_theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
     HIPCHK(h, hipMemsetAsync(p->ctl, 0, p->ctl_bytes, st));
 
     // A filter that fits one workgroup runs whole in ONE kernel (all observations ymin..ymax, everything between
@@ -435,13 +445,13 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         }
         p->initialised = true;
         HIPCHK(h, hipGetLastError());
-        std::vector<char> result(p->ctl_result_bytes);
-        HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
+        const char* const result_data = p->h_result;
+        HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         collect_timings_if_many(h);
-        if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
-        memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
-        if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
+        if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
+        memcpy(&h->last_events, result_data + (size_t)B * 8, 8);
+        if (out_status) memcpy(out_status, result_data + (size_t)B * 8 + 8, (size_t)B * 4);
         return DPOMP_OK;
     }
 
@@ -583,15 +593,15 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         t_prev = h->obs_time[k];  // :72
     }
     HIPCHK(h, hipGetLastError());
-    std::vector<char> result(p->ctl_result_bytes);
-    HIPCHK(h, hipMemcpyAsync(result.data(), p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
+    const char* const result_data = p->h_result;
+    HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     collect_timings_if_many(h);
-    if (out_ll) memcpy(out_ll, result.data(), (size_t)B * 8);
-    memcpy(&h->last_events, result.data() + (size_t)B * 8, 8);
-    if (out_status) memcpy(out_status, result.data() + (size_t)B * 8 + 8, (size_t)B * 4);
+    if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
+    memcpy(&h->last_events, result_data + (size_t)B * 8, 8);
+    if (out_status) memcpy(out_status, result_data + (size_t)B * 8 + 8, (size_t)B * 4);
     {
-        const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(result.data() + p->sched_offset);
+        const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(result_data + p->sched_offset);
         for (int k = ymin - 1; k < ymax; ++k) {
             const unsigned long long ev = sc[kSchedStride * k], slots = sc[kSchedStride * k + kSchedSlots];
             h->last_events += ev;  // the propagate kernels count events per interval
