@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="HIP-event brackets around the kernels of every n-th timed step (the markers cost GPU time)")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,7 +158,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    pf.set_profiling(True)  # HIP events around every kernel, on the launch stream
+    pf.set_profiling(max(1, args.profile_every))  # HIP events around the kernels of every n-th step, on the launch stream
     lls, events = [], 0
     fence()
     t0 = time.perf_counter()
@@ -200,8 +202,9 @@ def main():
             "frac": round(g.get("achieved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
             "traffic": (pmc_traffic("k_gather") or (None, None))[0],
             "traffic_source": (pmc_traffic("k_gather") or (None, "none"))[1],
-            "timing": f"HIP events on the launch stream around each launch (an EMPTY bracket reads {null_us:.1f} us here, so for "
-                      "~10 us kernels these durations are upper bounds; rocprofv3 dispatch times are in profiles/)",
+            "timing": f"HIP events on the launch stream around the launches of every {max(1, args.profile_every)}th timed step "
+                      f"(an EMPTY bracket reads {null_us:.1f} us here, so for ~10 us kernels "
+                      "these durations are upper bounds; rocprofv3 dispatch times are in profiles/)",
             "note": "memory-bound stage (normalise+scan+resample); k_propagate, which holds >95% of the "
                     "time, is FP64-VALU/divergence bound (SURVEY.md 8d) and is reported under 'propagate'",
         }

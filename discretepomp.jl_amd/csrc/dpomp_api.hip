@@ -130,7 +130,9 @@ struct dpomp_handle {
                         // many particles per lane; 16, 32 = compaction every that many events
     int rs_type = DPOMP_RS_SYSTEMATIC;
     double ess_frac = 0.0;  // > 0: ESS-adaptive resampling (dpomp_set_ess_threshold)
-    bool profiling = false;
+    bool profiling = false;        // brackets on for the current call
+    int profiling_every = 0;       // 0 = off, n = bracket the kernels of every n-th filter call
+    uint64_t profiled_calls = 0, call_counter = 0;
     double null_bracket_ms = 0.0;
     KernelStat stats[KID_COUNT];
     std::vector<hipEvent_t> event_pool;
@@ -206,6 +208,9 @@ hipEvent_t next_event(dpomp_handle* h) {
     return h->event_pool[h->events_used++];
 }
 
+// One timing bracket (two event markers) per kernel launch.  A marker costs ~1.5 us on the GPU timeline, which is why
+// profiling can be sampled (every n-th call).  Sharing the boundary marker between consecutive launches was tried: it
+// halves the markers but charges each kernel with the marker in front of it (k_gather 10.4 -> 11.1 us).
 struct ScopedTiming {
     dpomp_handle* h;
     int kid;
@@ -226,6 +231,12 @@ struct ScopedTiming {
         }
     }
 };
+// Decides whether this filter call is bracketed (dpomp_set_profiling(h, n): every n-th call).
+inline void begin_profiled_call(dpomp_handle* h) {
+    h->profiling = h->profiling_every > 0 && (h->call_counter % (uint64_t)h->profiling_every) == 0;
+    h->call_counter += 1;
+    if (h->profiling) h->profiled_calls += 1;
+}
 
 // Resolving a bracket costs a host call per kernel; doing it at the end of every filter call would leave the GPU idle
 // meanwhile, so brackets pile up (the calls are synchronous: their events have completed) and are resolved when the
@@ -392,6 +403,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     const int64_t B = p->B;
     const dim3 block(kBlock);
     const dim3 grid_tiles((unsigned)p->nblk, (unsigned)B);
+    begin_profiled_call(h);
 
     const bool adaptive = h->ess_frac > 0.0 && domain == DOMAIN_PROPAGATE;
     if (adaptive && !p->blocksum2) {
@@ -1192,7 +1204,9 @@ int dpomp_set_profiling(dpomp_handle* h, int on) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         collect_timings(h);
     }
-    h->profiling = on != 0;
+    h->profiling_every = on > 0 ? on : 0;
+    h->profiling = false;
+    h->call_counter = 0;
     if (on && h->null_bracket_ms == 0.0) {  // calibrate the bracket itself once
         HIPCHK(h, hipSetDevice(h->device));
         // 64 empty brackets enqueued back to back behind a kernel (a busy queue, as in a filter call), one

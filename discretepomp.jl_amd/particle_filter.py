@@ -250,8 +250,9 @@ class ParticleFilter:
         self._check(self._lib.dpomp_last_event_count(self._h, C.byref(ev)))
         return int(ev.value)
 
-    def set_profiling(self, on: bool):
-        self._check(self._lib.dpomp_set_profiling(self._h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False/0 = off; True/1 = time the kernels of every filter call; n > 1 = of every n-th call."""
+        self._check(self._lib.dpomp_set_profiling(self._h, int(on)))
 
     def null_bracket_us(self) -> float:
         """Median elapsed time of an empty HIP-event bracket (what profiling adds to each kernel's duration)."""
