@@ -71,6 +71,7 @@ struct PropArgs {
     int32_t n_yval;
     unsigned long long* sched;  // this interval's counters: [0] += executed events, [kSchedSlots] += sum over waves of 64 * (max events in wave)
 };
+constexpr int kQueueChunk = 16;  // events between two refill points of k_propagate_q
 constexpr int kSchedSlots = 16;   // u64 index of the second counter: 128 bytes after the first, i.e. another L2 line
 constexpr int kSchedStride = 32;  // u64 per observation interval
 
@@ -427,9 +428,9 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
 // first interval, 269 +- 16 later), so a wave runs until its slowest lane is done (measured lane
 // utilisation 79 %).  Here a workgroup owns a chunk of C = 256*RPL particles.  Phase 0 stages the
 // chunk in LDS with coalesced loads: state tile [S][C] and the Philox-seeded stream state of every
-// particle (full lane occupancy for the 10 Philox rounds).  Phase 1: lanes pop the next particle
-// index from an LDS queue whenever they finish one (LDS atomic + 2 LDS reads, no global memory, no
-// Philox), write the final state back to the LDS tile.  Phase 2: weights, coalesced write-back and
+// particle (full lane occupancy for the 10 Philox rounds).  Phase 1: every kQueueChunk events the lanes of a wave
+// that have finished their particle pop the next ones from the workgroup's LDS queue (one LDS atomic per wave, 2 LDS
+// reads per lane, no global memory, no Philox; no barrier), and write the final state back to the LDS tile.  Phase 2: weights, coalesced write-back and
 // the reductions, again at full occupancy.  Which lane runs which particle is irrelevant to the
 // result because every draw is keyed by the particle index: still bit-identical to the oracle.
 template <class R, int RPL>
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     __shared__ double s_max[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
     __shared__ int s_cap[kBlock / 64];
+    __shared__ int s_nmax[kBlock / 64];
 
     const int b = blockIdx.y;
     const int base = blockIdx.x * C;
@@ -482,51 +484,45 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     double time = 0.0;
     int n = 0, cur = 0;
     bool active = false, exhausted = false;
+    const int lane_q = threadIdx.x & 63;
     for (;;) {
-        if (!active && !exhausted) {
-            const int idx = atomicAdd(&s_next, 1);
-            if (idx < cnt) {
-                cur = idx;
+        // refill: the lanes of a wave that are out of work take the next particles of the workgroup's queue with one
+        // LDS atomic per wave
+        const unsigned long long need = wave_ballot(!active && !exhausted);
+        if (need) {
+            int first = 0;
+            if (lane_q == (int)__builtin_ctzll(need)) first = atomicAdd(&s_next, (int)__popcll(need));
+            first = __shfl(first, (int)__builtin_ctzll(need), 64);
+            if (!active && !exhausted) {
+                const int idx = first + (int)__popcll(need & ((1ull << lane_q) - 1ull));
+                if (idx < cnt) {
+                    cur = idx;
 #pragma unroll
-                for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
-                const uint4 sd = s_seed[idx];
-                rng = stream_start(StreamSeed{sd.x, sd.y, sd.z, sd.w});
-                time = t_start;
-                n = 0;
-                active = true;
-            } else {
-                exhausted = true;
+                    for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
+                    const uint4 sd = s_seed[idx];
+                    rng = stream_start(StreamSeed{sd.x, sd.y, sd.z, sd.w});
+                    time = t_start;
+                    n = 0;
+                    active = true;
+                } else {
+                    exhausted = true;
+                }
             }
         }
         if (!wave_any(active)) break;
-        if (active) {
-            double cum[E];
-            R::rates(a.m, thr, x, cum);
-#pragma unroll
-            for (int e = 1; e < E; ++e) cum[e] = cum[e - 1] + cum[e];
-            const double tot = cum[E - 1];
-            bool done = (tot == 0.0), capped = false;
-            if (!done) {
-                const double u1 = u01(stream_next(rng));
-                time = time - dlog_tab(u1, s_log) / tot;
-                done = time > tmax;
-                if (!done) {
-                    const double etc = u01(stream_next(rng)) * tot;
-                    TW tw = (TW)a.m.trans_packed[e_real - 1];
-#pragma unroll
-                    for (int i = E - 2; i >= 0; --i) {
-                        const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                        if (in_range && cum[i] > etc) tw = (TW)a.m.trans_packed[i];
-                    }
-#pragma unroll
-                    for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-                    if (++n >= cap) done = capped = true;
-                }
+        if (active) {  // up to QCHK events, then back to the refill point (a finished lane idles for the rest of the chunk)
+            int it = 0;
+            bool go;
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+            while (go && ++it < kQueueChunk);
+            if (!go && stopped_on_range(n, cap, time, tmax)) {
+                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+                while (go && ++it < kQueueChunk);
             }
-            if (done) {
+            if (!go) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) s_x[s][cur] = x[s];
-                s_cnt[cur] = n | (capped ? (int)0x80000000 : 0);
+                s_cnt[cur] = n | (stopped_on_cap(n, cap) ? (int)0x80000000 : 0);
                 active = false;
             }
         }
@@ -536,9 +532,11 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     double gmax = -__builtin_inf();
     unsigned long long ev = 0;
     bool any_cap = false;
+    int nmax_sum = 0;  // sum over this wave's RPL slot groups of the largest event count: the static schedule's waves
 #pragma unroll
     for (int jj = 0; jj < RPL; ++jj) {
         const int idx = jj * kBlock + threadIdx.x;
+        int pn = 0;
         if (idx < cnt) {
             const int p = base + idx;
             int xv[S];
@@ -549,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
             }
             const int c = s_cnt[idx];
             ev += (unsigned long long)(c & 0x7FFFFFFF);
+            pn = c & 0x7FFFFFFF;
             const bool capped = c < 0;
             any_cap |= capped;
             if (a.want_weight) {
@@ -559,6 +558,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
                 gmax = fmax(gmax, g);
             }
         }
+        nmax_sum += wave_max_i32(pn);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const double wm = wave_max(gmax);
@@ -568,21 +568,26 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         s_max[wid] = wm;
         s_ev[wid] = wev;
         s_cap[wid] = wcap;
+        s_nmax[wid] = nmax_sum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         double bm = s_max[0];
-        unsigned long long be = s_ev[0];
+        unsigned long long be = s_ev[0], bs = (unsigned long long)s_nmax[0];
         int bc = s_cap[0];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; ++w) {
             bm = fmax(bm, s_max[w]);
             be += s_ev[w];
+            bs += (unsigned long long)s_nmax[w];
             bc |= s_cap[w];
         }
         if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
-        if (be) atomicAdd(a.events, be);
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+        if (be) {
+            atomicAdd(&a.sched[0], be);
+            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
+        }
     }
 }
 
