@@ -5,7 +5,7 @@ y = dp.get_observations("tests/golden/pooley.csv")
 pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), y)
 for variant in (0, 1):
     pf.set_propagate_variant(variant)
-    for B, P in [(1, 64), (1, 200), (4, 512), (64, 200), (1000, 200), (4000, 200), (1, 1 << 14), (1, 1 << 17)]:
+    for B, P in [(1, 64), (1, 200), (4, 512), (4, 1000), (64, 200), (64, 1000), (1000, 200), (4000, 200), (1, 1 << 14), (1, 1 << 17)]:
         th = np.tile(np.array([[0.003], [0.1]]), (1, B))
         pf.loglik(th, P, seed=1)
         t = time.perf_counter(); n = 20
