@@ -286,10 +286,26 @@ struct TransRows {
 // stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
 // arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
 // stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
+// The two uniforms of an event do not depend on the state, only the division by the rate total does.  They are
+// therefore drawn -- and the logarithm of the first taken -- one event AHEAD: log(u) with its LDS table read then
+// runs beside the rates -> reciprocal -> Newton chain of the current event instead of in front of the division, which
+// shortens the dependent chain a lone wave walks per event (small filters, and the stragglers at the end of every
+// launch).  Event n still consumes draws 2n and 2n+1 of the particle's stream; the pair drawn ahead when a particle
+// stops is simply never used.
+struct Draws {
+    double lu, u2;  // log of the waiting-time uniform and the event-choice uniform of the NEXT event
+};
+__device__ __forceinline__ Draws draw_ahead(Stream& rng, const double (*s_log)[2]) {
+    Draws d;
+    d.lu = dlog_tab(u01(stream_next(rng)), s_log);
+    d.u2 = u01(stream_next(rng));
+    return d;
+}
+
 template <class R, bool FAST>
 __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRows<R> rows, const double* thr,
-                                                int (&x)[R::S], double& time, const double tmax, Stream& rng, int& n,
-                                                const int cap, const int e_real, const double (*s_log)[2]) {
+                                                int (&x)[R::S], double& time, const double tmax, Stream& rng, Draws& d,
+                                                int& n, const int cap, const int e_real, const double (*s_log)[2]) {
     constexpr int S = R::S, E = R::E;
     using TW = typename TransRows<R>::TW;
     double cum[E];
@@ -302,10 +318,11 @@ __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRo
     } else {
         if (tot == 0.0) return false;
     }
-    const double lu = dlog_tab(u01(stream_next(rng)), s_log);
-    time = time - (FAST ? div_in_range(lu, tot) : lu / tot);
+    const Draws now = d;
+    d = draw_ahead(rng, s_log);
+    time = time - (FAST ? div_in_range(now.lu, tot) : now.lu / tot);
     if (time > tmax) return false;
-    const double etc = u01(stream_next(rng)) * tot;
+    const double etc = now.u2 * tot;
     TW tw = rows.v[E - 1];
 #pragma unroll
     for (int i = E - 2; i >= 0; --i) {
@@ -368,9 +385,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     bool capped = false;
 
     if (valid) {
-        while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+        Draws ahead = draw_ahead(rng, s_log);
+        while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
         if (stopped_on_range(n, cap, time, tmax))
-            while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
         capped = stopped_on_cap(n, cap);
     }
 
@@ -481,6 +499,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] = 0;
     Stream rng{0, 0, 0, 0};
+    Draws ahead{0.0, 0.0};
     double time = 0.0;
     int n = 0, cur = 0;
     bool active = false, exhausted = false;
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
                     for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
                     const uint4 sd = s_seed[idx];
                     rng = stream_start(StreamSeed{sd.x, sd.y, sd.z, sd.w});
+                    ahead = draw_ahead(rng, s_log);
                     time = t_start;
                     n = 0;
                     active = true;
@@ -513,10 +533,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         if (active) {  // up to QCHK events, then back to the refill point (a finished lane idles for the rest of the chunk)
             int it = 0;
             bool go;
-            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
             while (go && ++it < kQueueChunk);
             if (!go && stopped_on_range(n, cap, time, tmax)) {
-                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
                 while (go && ++it < kQueueChunk);
             }
             if (!go) {
@@ -608,16 +628,17 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
     __shared__ int32_t s_cnt[kBlock];     // executed events, bit 31 = event cap
     // Compaction staging.  A compaction frees at least one wave, so at most kBlock - 64 contexts move; they go
-    // through one buffer in two passes (stream words, then state/clock/counters) to keep the workgroup's LDS
-    // small enough for 8 workgroups per CU with room to spare.
+    // through one 6 KB buffer in three passes of 32 bytes per context (stream words; clock, counters and the draws made
+    // ahead; state) to keep the workgroup's LDS small enough for 8 workgroups per CU whatever the model.
     constexpr int kLive = kBlock - 64;
-    constexpr int kCtxBytes = (S * 4 + 16) > 32 ? (S * 4 + 16) : 32;
+    constexpr int kCtxBytes = 32;  // per pass: stream words (32), clock + counters + draws ahead (32), state (4 S <= 32)
     __shared__ __attribute__((aligned(16))) unsigned char c_raw[kCtxBytes * kLive];
     uint4* const c_rng0 = reinterpret_cast<uint4*>(c_raw);
     uint4* const c_rng1 = c_rng0 + kLive;
     double* const c_time = reinterpret_cast<double*>(c_raw);
     int2* const c_nc = reinterpret_cast<int2*>(c_raw + 8 * kLive);
-    int32_t* const c_x = reinterpret_cast<int32_t*>(c_raw + 16 * kLive);  // [S][kLive]
+    double2* const c_ahead = reinterpret_cast<double2*>(c_raw + 16 * kLive);  // the draws made one event ahead
+    int32_t* const c_x = reinterpret_cast<int32_t*>(c_raw);                    // [S][kLive], third pass
     __shared__ int s_wcnt[2][kBlock / 64];
     __shared__ double s_max[kBlock / 64];
     __shared__ unsigned long long s_ev[kBlock / 64];
@@ -649,15 +670,16 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
     bool parked = !valid; // final state already parked in s_res
     bool capped = false;
     __syncthreads();
+    Draws ahead = draw_ahead(rng, s_log);  // (after the barrier: reads the log table in LDS)
 
     for (int round = 0;; ++round) {
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             int it = 0;
             bool go;
-            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
             while (go && ++it < CHK);
             if (!go && stopped_on_range(n, cap, time, tmax)) {
-                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log);
+                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
                 while (go && ++it < CHK);
             }
             active = go;
@@ -695,11 +717,26 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
                 moved.n = (uint64_t)r5.z | ((uint64_t)r5.w << 32);
             }
             __syncthreads();
-            if (active) {
-#pragma unroll
-                for (int s = 0; s < S; ++s) c_x[s * kLive + rank] = x[s];
+            if (active) {  // pass 2: clock, counters, the draws made ahead
                 c_time[rank] = time;
                 c_nc[rank] = make_int2(n, cur);
+                c_ahead[rank] = make_double2(ahead.lu, ahead.u2);
+            }
+            __syncthreads();
+            double moved_time = time;
+            Draws moved_ahead = ahead;
+            int2 moved_nc = make_int2(n, cur);
+            if (take) {
+                moved_time = c_time[threadIdx.x];
+                const double2 ah = c_ahead[threadIdx.x];
+                moved_ahead.lu = ah.x;
+                moved_ahead.u2 = ah.y;
+                moved_nc = c_nc[threadIdx.x];
+            }
+            __syncthreads();
+            if (active) {  // pass 3: the state
+#pragma unroll
+                for (int s = 0; s < S; ++s) c_x[s * kLive + rank] = x[s];
             }
             __syncthreads();
             active = take;
@@ -708,10 +745,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) x[s] = c_x[s * kLive + threadIdx.x];
                 rng = moved;
-                time = c_time[threadIdx.x];
-                const int2 nc = c_nc[threadIdx.x];
-                n = nc.x;
-                cur = nc.y;
+                time = moved_time;
+                ahead = moved_ahead;
+                n = moved_nc.x;
+                cur = moved_nc.y;
             }
         }
     }
@@ -840,9 +877,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         int n = 0;
         bool capped = false;
         if (valid) {
-            while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+            Draws ahead = draw_ahead(rng, s_log);
+            while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
             if (stopped_on_range(n, cap, time, tmax))
-                while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, n, cap, e_real, s_log)) {}
+                while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
             capped = stopped_on_cap(n, cap);
         }
         ev += (unsigned long long)n;
