@@ -159,6 +159,11 @@ class ParticleFilter:
         """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
         self._check(self._lib.dpomp_set_stream(self._h, C.c_void_p(raw_stream or 0)))
 
+    def set_resampler(self, rs_type: int):
+        """1 systematic (the reference's working default), 2 stratified, 3 multinomial."""
+        self._check(self._lib.dpomp_set_resampler(self._h, int(rs_type)))
+        self.rs_type = int(rs_type)
+
     def set_ess_threshold(self, ess_frac: float):
         """ESS-adaptive resampling (0 = the reference's behaviour: resample at every weighted observation)."""
         self._check(self._lib.dpomp_set_ess_threshold(self._h, float(ess_frac)))
