@@ -576,3 +576,27 @@ def test_event_loop_division_is_the_ieee_quotient(sis):
     with np.errstate(divide="ignore", invalid="ignore"):
         want = -1.0 / out
     assert np.array_equal(plain, want, equal_nan=True)
+
+
+def test_sampled_profiling_brackets_every_nth_call(dp, pooley):
+    """dpomp_set_profiling(h, n): kernels of every n-th filter call are timed; statistics are resolved lazily when
+    they are read and survive switching profiling off."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    theta = np.array([[0.003], [0.1]])
+    pf.loglik(theta, 4096, seed=1)
+    assert all(n == 0 for n, _ in pf.kernel_stats().values())
+    pf.set_profiling(2)
+    for s in range(4):
+        pf.loglik(theta, 4096, seed=s)
+    st = pf.kernel_stats()
+    assert st["k_propagate"][0] == 2 * pf.n_obs and st["k_init"][0] == 2      # calls 0 and 2 of the four
+    assert st["k_gather"][0] == 2 * (pf.n_obs - 1) and st["k_propagate"][1] > 0.0
+    pf.set_profiling(False)
+    pf.loglik(theta, 4096, seed=9)
+    assert pf.kernel_stats()["k_propagate"][0] == 2 * pf.n_obs
+    pf.set_profiling(True)
+    pf.loglik(theta, 4096, seed=9)
+    assert pf.kernel_stats()["k_propagate"][0] == 3 * pf.n_obs
+    with pytest.raises(dp.DpompError):
+        pf._check(pf._lib.dpomp_get_lane_utilisation(pf._h, pf.n_obs + 1, __import__("ctypes").byref(__import__("ctypes").c_double())))
+    pf.close()
