@@ -140,16 +140,26 @@ def main():
     if args.propagate_variant:
         pf.set_propagate_variant(args.propagate_variant)
     P, T, S = args.particles, len(y), model.n_states
-    gathered = torch.zeros(world, dtype=torch.float64, device="cuda")
-    mine = torch.zeros(1, dtype=torch.float64, device="cuda")
+    n_calls = args.warmup + args.steps
+    # The only collective of the path: the log-ML estimates of the independent filters (chains), all-gathered over
+    # RCCL.  The chains do not wait for each other's estimates, so the all-gather of step i is asynchronous and
+    # overlaps the filter of step i+1; every handle is waited for before the closing fence of the timed region.
+    gathered = torch.zeros((n_calls, world), dtype=torch.float64, device="cuda")
+    mine_host = torch.zeros(n_calls, dtype=torch.float64).pin_memory() if dist is not None else None
+    mine_dev = torch.zeros(n_calls, dtype=torch.float64, device="cuda")
+    pending = []
 
     def step(i):
         ll = pf.loglik(THETA, P, seed=1000 + i, seg_base=rank)
-        if dist is not None:  # the only collective of the path: log-ML estimates of the independent filters
-            mine[0] = float(ll[0])
-            dist.all_gather_into_tensor(gathered, mine)
-            return gathered
+        if dist is not None:
+            mine_host[i] = float(ll[0])
+            mine_dev[i:i + 1].copy_(mine_host[i:i + 1], non_blocking=True)
+            pending.append(dist.all_gather_into_tensor(gathered[i], mine_dev[i:i + 1], async_op=True))
         return ll
+
+    def drain():
+        while pending:
+            pending.pop().wait()
 
     def fence():
         if dist is not None:
@@ -158,17 +168,24 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     pf.set_profiling(max(1, args.profile_every))  # HIP events around the kernels of every n-th step, on the launch stream
     lls, events = [], 0
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
-        lls.append(float(out[rank]) if dist is not None else float(out[0]))
+        lls.append(float(out[0]))
         events += pf.last_event_count()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
     pf.set_profiling(False)
+    ll_all_ranks = None
+    if dist is not None:  # the gathered estimates: this rank's column must be what its filter returned
+        got = gathered[args.warmup:].cpu().numpy()
+        assert np.array_equal(got[:, rank], np.array(lls)), "all-gathered log-ML differs from the local result"
+        ll_all_ranks = float(got.mean())
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -242,7 +259,7 @@ def main():
                        "parallelism": f"{world} independent filters, all-gather of log-ML" if world > 1 else "single filter"},
             "events_per_s": events / elapsed,
             "log_ml": {"mean": mean_ll, "exact": EXACT_LL, "abs_err_vs_exact": abs(mean_ll - EXACT_LL),
-                       "sd_over_steps": float(np.std(lls))},
+                       "sd_over_steps": float(np.std(lls)), "mean_over_all_ranks": ll_all_ranks},
             "roofline": roofline,
             "propagate": propagate,
             "kernels": kernels,
