@@ -256,6 +256,29 @@ function gather!(pop::Population, ancestors::Vector{Int64})
                                               pop.f.handle, pop.ptr, a0))
 end
 
+"""
+    take!(dst, src, take)
+
+Accepted PMMH proposals (src/hmm_ibis.jl:109, `pop[p] .= pop_f`): segment `p` of `dst` becomes segment `take[p]` of
+`src` (1-based; 0 = keep `dst[p]`).
+"""
+function take!(dst::Population, src::Population, take::Vector{Int64})
+    t0 = take .- 1            # the ABI is 0-based, -1 = keep
+    GC.@preserve t0 check(dst.f.handle, ccall((:dpomp_pop_take, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}),
+                                              dst.f.handle, dst.ptr, src.ptr, t0))
+end
+
+"Lane utilisation of each observation interval in the last call (what the automatic kernel schedule decides on)."
+function lane_utilisation(f::Filter)
+    out = Vector{Float64}(undef, f.n_obs)
+    u = Ref(0.0)
+    for k in 1:f.n_obs
+        check(f.handle, ccall((:dpomp_get_lane_utilisation, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}), f.handle, k, u))
+        out[k] = u[]
+    end
+    return out
+end
+
 "Segment b (1-based) as the reference's P x S `Array{Int64,2}`."
 function download(pop::Population, b::Integer, S::Integer)
     out = Array{Int64,2}(undef, pop.P, S)
