@@ -600,3 +600,35 @@ def test_sampled_profiling_brackets_every_nth_call(dp, pooley):
     with pytest.raises(dp.DpompError):
         pf._check(pf._lib.dpomp_get_lane_utilisation(pf._h, pf.n_obs + 1, __import__("ctypes").byref(__import__("ctypes").c_double())))
     pf.close()
+
+
+@pytest.mark.parametrize("name,x0,fd,theta", [c for c in CASES if c[0] in ("SEIR", "LOTKA", "ROSSMAC", "SIR")])
+def test_catalogue_models_at_chip_filling_size_all_schedules_agree(dp, orc, name, x0, fd, theta):
+    """2^19 particles (8192 waves: the automatic schedule runs workgroup compaction): compaction, static and the LDS
+    queue return the same log-likelihood, populations and event count, for 3- and 4-component states and 2 to 6 event
+    types; the first observation (propagation, weights, resampling) is also checked against the oracle at full size."""
+    model = dp.generate_model(name, x0, freq_dep=fd)
+    y = _synthetic_data(dp, orc, model, theta)
+    pf = dp.ParticleFilter(model, y)
+    P = 1 << 19
+    th = np.array(theta)[:, None]
+    out = {}
+    for variant in (0, 1, 2):
+        pf.set_propagate_variant(variant)
+        pop = pf.alloc_population(1, P)
+        ll = pf.partial_log_likelihood(pop, th, 1, len(y), seed=5)
+        out[variant] = (ll[0], pop.download(0), pf.last_event_count(), int(pf.last_status[0]))
+        pop.close()
+    for variant in (1, 2):
+        assert out[variant][0] == out[0][0] and out[variant][2] == out[0][2] and out[variant][3] == out[0][3]
+        assert np.array_equal(out[variant][1], out[0][1])
+    assert np.isfinite(out[0][0]) and out[0][3] == 0
+    # and the oracle at the same size for the first observation (propagate + weights + resampling)
+    pf.set_propagate_variant(0)
+    pop = pf.alloc_population(1, P)
+    ll1 = pf.partial_log_likelihood(pop, th, 1, 1, seed=5)
+    host = np.zeros((P, model.n_states), dtype=np.int64)
+    ref = orc.pf_partial(pf.desc, host, theta, 1, 1, seed=5, nthreads=8)
+    assert ll1[0] == ref.ll and pf.last_event_count() == ref.events
+    assert np.array_equal(pop.download(0), host)
+    pf.close()
