@@ -536,8 +536,9 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
             do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
             while (go && ++it < kQueueChunk);
             if (!go && stopped_on_range(n, cap, time, tmax)) {
+                int it2 = 0;
                 do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-                while (go && ++it < kQueueChunk);
+                while (go && ++it2 < kQueueChunk);
             }
             if (!go) {
 #pragma unroll
@@ -678,9 +679,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
             bool go;
             do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
             while (go && ++it < CHK);
-            if (!go && stopped_on_range(n, cap, time, tmax)) {
+            if (!go && stopped_on_range(n, cap, time, tmax)) {  // (own trip counter: keeping `it` alive per lane costs two
+                int it2 = 0;                                       //  v_mov per event in the fast loop)
                 do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-                while (go && ++it < CHK);
+                while (go && ++it2 < CHK);
             }
             active = go;
             capped = stopped_on_cap(n, cap);
