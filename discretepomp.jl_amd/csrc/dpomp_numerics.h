@@ -86,7 +86,7 @@ DPOMP_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 // shift-add are single v_lshl_add_u64 instructions, ~11 VALU ops per 64 random bits (xoroshiro128++ needs ~19).
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device form of the same step.  c + (c << 3) is pinned to one v_lshl_add_u64 (the compiler otherwise rewrites it
-// as c * 9 and emits quarter-rate v_mad_u64_u32 pairs); the rotate is two v_alignbit_b32 on the 32-bit halves.
+// as c * 9 and emits quarter-rate v_mad_u64_u32 pairs).
 __device__ __forceinline__ uint64_t stream_next(Stream& s) {
     const uint64_t t = s.a + s.b + s.n;
     s.n += 1;
@@ -94,9 +94,8 @@ __device__ __forceinline__ uint64_t stream_next(Stream& s) {
     uint64_t nb;
     asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(nb) : "v"(s.c));
     s.b = nb;
-    const uint32_t c_lo = (uint32_t)s.c, c_hi = (uint32_t)(s.c >> 32);
-    const uint32_t r_hi = __builtin_amdgcn_alignbit(c_hi, c_lo, 8), r_lo = __builtin_amdgcn_alignbit(c_lo, c_hi, 8);
-    s.c = (((uint64_t)r_hi << 32) | r_lo) + t;
+    s.c = ((s.c << 24) | (s.c >> 40)) + t;  // the compiler's own rotate (64-bit shift, 32-bit shift, or) + one add:
+                                            // assembling it from two v_alignbit halves costs a v_mov and a second add
     return t;
 }
 #else
