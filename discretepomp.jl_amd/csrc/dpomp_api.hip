@@ -355,8 +355,8 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     // result download per call
     {
         const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
-        // per observation: executed events and 64 * sum of per-wave maxima, each counter in a 128-byte line of its own
-        // (two atomics of one workgroup on the same line cost ~9 ns each at the L2; on separate lines they are free)
+        // per observation: executed events and 64 * sum of per-wave maxima, as partial sums on 128-byte lines of their
+        // own (dpomp_kernels.h: sched_add)
         const size_t n_sc = (size_t)p->T * kSchedStride * 8;
         p->sched_offset = n_ll + n_ev + n_st;
         p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
@@ -615,7 +615,11 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     {
         const unsigned long long* sc = reinterpret_cast<const unsigned long long*>(result_data + p->sched_offset);
         for (int k = ymin - 1; k < ymax; ++k) {
-            const unsigned long long ev = sc[kSchedStride * k], slots = sc[kSchedStride * k + kSchedSlots];
+            unsigned long long ev = 0, slots = 0;
+            for (int s2 = 0; s2 < kSchedSlots; ++s2) {
+                ev += sc[kSchedStride * k + s2 * kSchedLine];
+                slots += sc[kSchedStride * k + (kSchedSlots + s2) * kSchedLine];
+            }
             h->last_events += ev;  // the propagate kernels count events per interval
             if (slots && domain == DOMAIN_PROPAGATE) h->lane_util[k] = (double)ev / (double)slots;
         }

@@ -69,11 +69,29 @@ struct PropArgs {
     const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
     const long long* yval;    // [V] Observation.val of this observation (user observation models)
     int32_t n_yval;
-    unsigned long long* sched;  // this interval's counters: [0] += executed events, [kSchedSlots] += sum over waves of 64 * (max events in wave)
+    unsigned long long* sched;  // this interval's counters, see sched_add()
 };
+// The workgroups of a launch publish their maximum log-weight into one word per filter.  Thousands of atomics on one
+// address serialise at the L2 (~9 ns each: 37 us for the 4096 workgroups of a 2^20-particle filter, most of a launch
+// in which little happens), but the maximum is established by the first few workgroups: read it first and only the
+// record breakers issue the atomic.  (A stale, smaller value read from a cache merely causes a redundant atomic.)
+__device__ __forceinline__ void publish_max(unsigned long long* slot, unsigned long long key) {
+    if (key > __atomic_load_n(slot, __ATOMIC_RELAXED)) atomicMax(slot, key);
+}
 constexpr int kQueueChunk = 16;  // events between two refill points of k_propagate_q
-constexpr int kSchedSlots = 16;   // u64 index of the second counter: 128 bytes after the first, i.e. another L2 line
-constexpr int kSchedStride = 32;  // u64 per observation interval
+// Per-interval counters: executed events, and the sum over waves of 64 * (largest event count in the wave) -- what a
+// one-particle-per-lane schedule makes of the interval (dpomp_get_lane_utilisation).  Every workgroup adds to both,
+// and atomics that share a 128-byte line serialise at the L2 (~9 ns each; two counters side by side cost a
+// 4096-workgroup launch 70 us).  Each counter is therefore kSchedSlots partial sums on lines of their own, the slot
+// chosen by the workgroup index; the host adds them up.
+constexpr int kSchedSlots = 8;
+constexpr int kSchedLine = 16;                             // u64 per 128-byte line
+constexpr int kSchedStride = 2 * kSchedSlots * kSchedLine;  // u64 per observation interval
+__device__ __forceinline__ void sched_add(unsigned long long* sched, unsigned long long events, unsigned long long slots) {
+    const int s = (int)(blockIdx.x & (kSchedSlots - 1));
+    atomicAdd(&sched[s * kSchedLine], events);
+    atomicAdd(&sched[(kSchedSlots + s) * kSchedLine], slots);
+}
 
 // ---- rate evaluators (the pluggable part) -------------------------------------------------
 // Each evaluator restates one reference rate function with the same association order:
@@ -432,11 +450,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
             bs += (unsigned long long)s_nmax[w];
             bc |= s_cap[w];
         }
-        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (a.want_weight && bm > -__builtin_inf()) publish_max(&a.segmax[b], ordered_key(bm));
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
         if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
-            atomicAdd(&a.sched[0], be);
-            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
+            sched_add(a.sched, be, 64ull * bs);
         }
     }
 }
@@ -603,11 +620,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
             bs += (unsigned long long)s_nmax[w];
             bc |= s_cap[w];
         }
-        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (a.want_weight && bm > -__builtin_inf()) publish_max(&a.segmax[b], ordered_key(bm));
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
         if (be) {
-            atomicAdd(&a.sched[0], be);
-            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
+            sched_add(a.sched, be, 64ull * bs);
         }
     }
 }
@@ -798,11 +814,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
             bs += (unsigned long long)s_wcnt[0][w];
             bc |= s_cap[w];
         }
-        if (a.want_weight && bm > -__builtin_inf()) atomicMax(&a.segmax[b], ordered_key(bm));
+        if (a.want_weight && bm > -__builtin_inf()) publish_max(&a.segmax[b], ordered_key(bm));
         if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
         if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
-            atomicAdd(&a.sched[0], be);
-            atomicAdd(&a.sched[kSchedSlots], 64ull * bs);
+            sched_add(a.sched, be, 64ull * bs);
         }
     }
 }
