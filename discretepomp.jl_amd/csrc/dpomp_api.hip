@@ -457,8 +457,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         }
         p->initialised = true;
         HIPCHK(h, hipGetLastError());
-        const char* const result_data = p->h_result;
-        HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
+        const char* const result_data = p->h_result;  // (the per-interval counters behind sched_offset are not used here)
+        HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->sched_offset, hipMemcpyDeviceToHost, st));
         HIPCHK(h, hipStreamSynchronize(st));
         collect_timings_if_many(h);
         if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
