@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
 // epilogue (weights, coalesced write-back, reductions) runs at full occupancy.  The arithmetic of
 // a particle does not depend on the lane it runs in, so results stay bit-identical.
 template <class R, int CHK>
-__global__ __launch_bounds__(kBlock) void k_propagate_c(PropArgs a) {
+__global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 waves per SIMD: at most 64 VGPRs
     constexpr int S = R::S, E = R::E;
     using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     __shared__ double s_log[kLogTableSize][2];
