@@ -196,7 +196,6 @@ def main():
 
     if rank == 0:
         stats = pf.kernel_stats()
-        null_us = pf.null_bracket_us()  # an empty event bracket, for information: NOT subtracted (it is not additive)
         alg = algorithmic_bytes(P, S)
         kernels = {}
         for name, (n, ms) in stats.items():
@@ -219,9 +218,9 @@ def main():
             "frac": round(g.get("achieved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
             "traffic": (pmc_traffic("k_gather") or (None, None))[0],
             "traffic_source": (pmc_traffic("k_gather") or (None, "none"))[1],
-            "timing": f"HIP events on the launch stream around the launches of every {max(1, args.profile_every)}th timed step "
-                      f"(an EMPTY bracket reads {null_us:.1f} us here, so for ~10 us kernels "
-                      "these durations are upper bounds; rocprofv3 dispatch times are in profiles/)",
+            "timing": f"HIP events stamped with each kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the "
+                      f"launch stream), kernels of every {max(1, args.profile_every)}th timed step; the same quantity rocprofv3 reports per "
+                      "dispatch (profiles/)",
             "note": "memory-bound stage (normalise+scan+resample); k_propagate, which holds >95% of the "
                     "time, is FP64-VALU/divergence bound (SURVEY.md 8d) and is reported under 'propagate'",
         }

@@ -2,6 +2,7 @@
 // (partial_log_likelihood!, src/hmm_particle_filter.jl:39-76, as a stream of kernel launches
 // over a device-resident population; no host synchronisation inside a call).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -208,29 +209,36 @@ hipEvent_t next_event(dpomp_handle* h) {
     return h->event_pool[h->events_used++];
 }
 
-// One timing bracket (two event markers) per kernel launch.  A marker costs ~1.5 us on the GPU timeline, which is why
-// profiling can be sampled (every n-th call).  Sharing the boundary marker between consecutive launches was tried: it
-// halves the markers but charges each kernel with the marker in front of it (k_gather 10.4 -> 11.1 us).
-struct ScopedTiming {
-    dpomp_handle* h;
-    int kid;
-    hipEvent_t e0 = nullptr;
-    ScopedTiming(dpomp_handle* h_, int kid_) : h(h_), kid(kid_) {
-        if (h->profiling) {
-            e0 = next_event(h);
-            if (e0) (void)hipEventRecord(e0, h->stream);
+// Per-kernel timing: when a call is profiled its kernels are launched with hipExtLaunchKernelGGL /
+// hipExtModuleLaunchKernel, which stamp a start and a stop event with the kernel's OWN begin and end (what rocprofv3
+// reports as the dispatch duration), instead of bracketing the launch with two hipEventRecord markers: those cost
+// ~1.5 us each on the GPU timeline and their bracket includes the launch gap (k_gather read 10.4 us in a bracket,
+// 8.0 us under rocprofv3).
+template <class F, class... Args>
+void timed_launch(dpomp_handle* h, int kid, F kernel, dim3 grid, dim3 block, unsigned shmem, hipStream_t st, Args... args) {
+    if (h->profiling) {
+        hipEvent_t e0 = next_event(h), e1 = next_event(h);
+        if (e0 && e1) {
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, e0, e1, 0, args...);
+            h->pending.push_back({kid, e0, e1});
+            return;
         }
     }
-    ~ScopedTiming() {
-        if (h->profiling && e0) {
-            hipEvent_t e1 = next_event(h);
-            if (e1) {
-                (void)hipEventRecord(e1, h->stream);
-                h->pending.push_back({kid, e0, e1});
-            }
+    hipLaunchKernelGGL(kernel, grid, block, shmem, st, args...);
+}
+// Run-time compiled kernels (module functions); `params` as for hipModuleLaunchKernel.
+hipError_t timed_module_launch(dpomp_handle* h, int kid, hipFunction_t f, dim3 grid, dim3 block, hipStream_t st, void** params) {
+    if (h->profiling) {
+        hipEvent_t e0 = next_event(h), e1 = next_event(h);
+        if (e0 && e1) {
+            const hipError_t e = hipExtModuleLaunchKernel(f, grid.x * block.x, grid.y * block.y, grid.z * block.z, block.x, block.y,
+                                                          block.z, 0, st, params, nullptr, e0, e1, 0);
+            if (e == hipSuccess) h->pending.push_back({kid, e0, e1});
+            return e;
         }
     }
-};
+    return hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, st, params, nullptr);
+}
 // Decides whether this filter call is bracketed (dpomp_set_profiling(h, n): every n-th call).
 inline void begin_profiled_call(dpomp_handle* h) {
     h->profiling = h->profiling_every > 0 && (h->call_counter % (uint64_t)h->profiling_every) == 0;
@@ -447,12 +455,11 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         sa.seg_base = (uint32_t)seg_base;
         sa.seed = seed;
         {
-            ScopedTiming tm(h, KID_FILTER_SMALL);
             if (h->rtc) {
                 void* params[] = {&sa};
-                HIPCHK(h, hipModuleLaunchKernel(h->rtc_small, (unsigned)B, 1, 1, kBlock, 1, 1, 0, st, params, nullptr));
+                HIPCHK(h, timed_module_launch(h, KID_FILTER_SMALL, h->rtc_small, dim3((unsigned)B), block, st, params));
             } else {
-                hipLaunchKernelGGL(h->prop.small, dim3((unsigned)B), block, 0, st, sa);
+                timed_launch(h, KID_FILTER_SMALL, h->prop.small, dim3((unsigned)B), block, 0, st, sa);
             }
         }
         p->initialised = true;
@@ -468,8 +475,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     }
 
     if (ymin == 1) {  // pop[i,:] .= initial_condition  (:41-45)
-        ScopedTiming tm(h, KID_INIT);
-        hipLaunchKernelGGL(k_init, grid_tiles, block, 0, st, h->dm, p->state[p->cur], p->Pp);
+        timed_launch(h, KID_INIT, k_init, grid_tiles, block, 0, st, h->dm, p->state[p->cur], p->Pp);
         p->initialised = true;
     }
     double t_prev = (ymin == 1) ? 0.0 : h->obs_time[ymin - 2];  // :45-47
@@ -510,7 +516,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                           ? kDefaultPropVariant : 1;  // lane_util = -1 (not measured yet) -> compaction
             if (h->rtc && rpl != 32) rpl = 1;  // run-time compiled models come in two variants
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
-            ScopedTiming tm(h, KID_PROPAGATE);  // iterate_particles! :56
+            // iterate_particles! :56
             HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
         }
         if (record_states)
@@ -549,20 +555,19 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.seg_base = (uint32_t)seg_base;
             w.seed = seed;
             {
-                ScopedTiming tm(h, KID_WSUM);
-                hipLaunchKernelGGL(k_wsum, grid_tiles, block, 0, st, w);
+                timed_launch(h, KID_WSUM, k_wsum, grid_tiles, block, 0, st, w);
             }
             const bool resample = obs_i < T;  // :62  (the ESS criterion is commented out in the reference, :63-68)
             const bool fused = resample && p->nblk <= kFusedScanMaxTiles;
             if (!fused) {
-                ScopedTiming tm(h, KID_SCAN_BLOCKS);  // output += log(cum_weight[end]/P)  :60
-                hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)B), block, 0, st, w);
+                // output += log(cum_weight[end]/P)  :60
+                timed_launch(h, KID_SCAN_BLOCKS, k_scan_blocks, dim3((unsigned)B), block, 0, st, w);
             }
             if (resample) {
                 {
-                    ScopedTiming tm(h, KID_OFFSETS);  // fused: also the tile-sum scan and the :60 update
-                    if (fused) hipLaunchKernelGGL(k_offsets<true>, grid_tiles, block, 0, st, w);
-                    else hipLaunchKernelGGL(k_offsets<false>, grid_tiles, block, 0, st, w);
+                    // fused: also the tile-sum scan and the :60 update
+                    if (fused) timed_launch(h, KID_OFFSETS, k_offsets<true>, grid_tiles, block, 0, st, w);
+                    else timed_launch(h, KID_OFFSETS, k_offsets<false>, grid_tiles, block, 0, st, w);
                 }
                 if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
                     GatherPosArgs gp;
@@ -579,8 +584,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                     gp.obs_k = (uint32_t)k;
                     gp.seg_base = (uint32_t)seg_base;
                     gp.seed = seed;
-                    ScopedTiming tm(h, KID_GATHER);
-                    hipLaunchKernelGGL(k_gather_pos, grid_tiles, block, (size_t)p->nblk * 8, st, gp);
+                    timed_launch(h, KID_GATHER, k_gather_pos, grid_tiles, block, (unsigned)((size_t)p->nblk * 8), st, gp);
                     p->cur ^= 1;
                     t_prev = h->obs_time[k];
                     continue;
@@ -596,8 +600,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                 g.S = p->S;
                 g.nblk = p->nblk;
                 {
-                    ScopedTiming tm(h, KID_GATHER);  // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67
-                    hipLaunchKernelGGL(k_gather, grid_tiles, block, 0, st, g);
+                    // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67
+                    timed_launch(h, KID_GATHER, k_gather, grid_tiles, block, 0, st, g);
                 }
                 p->cur ^= 1;
             }
@@ -730,11 +734,10 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
 hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a) {
     if (h->rtc) {
         void* params[] = {&a};
-        return hipModuleLaunchKernel(variant == 32 ? h->rtc_propc : h->rtc_prop1, grid.x, grid.y, grid.z, block.x, block.y,
-                                     block.z, 0, st, params, nullptr);
+        return timed_module_launch(h, KID_PROPAGATE, variant == 32 ? h->rtc_propc : h->rtc_prop1, grid, block, st, params);
     }
     PropFn fn = variant == 4 ? h->prop.q4 : variant == 2 ? h->prop.q2 : variant == 16 ? h->prop.c16 : variant == 32 ? h->prop.c32 : h->prop.fn1;
-    hipLaunchKernelGGL(fn, grid, block, 0, st, a);
+    timed_launch(h, KID_PROPAGATE, fn, grid, block, 0, st, a);
     return hipGetLastError();
 }
 
@@ -983,9 +986,8 @@ int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
     HIPCHK(h, hipMemcpyAsync(p->ancestors, ancestors, (size_t)p->B * 8, hipMemcpyHostToDevice, h->stream));
     const int64_t seg_ints = (int64_t)p->S * p->Pp;
     {
-        ScopedTiming tm(h, KID_COPYSEG);
-        hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)p->B), dim3(kBlock), 0,
-                           h->stream, (const int32_t*)p->state[p->cur], p->state[p->cur ^ 1], (const int64_t*)p->ancestors, seg_ints);
+        timed_launch(h, KID_COPYSEG, k_copy_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)p->B), dim3(kBlock), 0,
+                     h->stream, (const int32_t*)p->state[p->cur], p->state[p->cur ^ 1], (const int64_t*)p->ancestors, seg_ints);
     }
     p->cur ^= 1;
     HIPCHK(h, hipGetLastError());
@@ -1008,9 +1010,8 @@ int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const 
     HIPCHK(h, hipMemcpyAsync(dst->ancestors, take, (size_t)dst->B * 8, hipMemcpyHostToDevice, h->stream));
     const int64_t seg_ints = (int64_t)dst->S * dst->Pp;
     {
-        ScopedTiming tm(h, KID_COPYSEG);
-        hipLaunchKernelGGL(k_take_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)dst->B), dim3(kBlock), 0, h->stream,
-                           (const int32_t*)src->state[src->cur], dst->state[dst->cur], (const int64_t*)dst->ancestors, seg_ints);
+        timed_launch(h, KID_COPYSEG, k_take_segments, dim3((unsigned)(seg_ints / kTile), (unsigned)dst->B), dim3(kBlock), 0, h->stream,
+                     (const int32_t*)src->state[src->cur], dst->state[dst->cur], (const int64_t*)dst->ancestors, seg_ints);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -247,8 +247,8 @@ int dpomp_selftest_division(dpomp_handle* h, int64_t n, const double* a_in, cons
                             double* out_plain);
 
 /* Per-kernel HIP-event timing on the launch stream, accumulated while profiling is on.  on = 0 switches it off,
- * on = n > 0 brackets the kernels of every n-th filter call (n = 1: every call); the markers cost ~1.5 us each on the
- * GPU timeline, so sampling keeps a long timed run close to its un-instrumented speed. */
+ * on = n > 0 times the kernels of every n-th filter call (n = 1: every call).  Timed kernels are launched with start
+ * and stop events that carry the kernel's own begin and end (the dispatch duration rocprofv3 reports). */
 int dpomp_set_profiling(dpomp_handle* h, int on);
 int dpomp_kernel_count(void);
 const char* dpomp_kernel_name(int kernel_id);
