@@ -128,3 +128,20 @@ def test_user_obs_model_filter_matches_oracle(dp, orc, pooley, tmp_path, P):
         assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
     pf.close()
     orc.set_user_rates_from_source(SOURCE, str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_rate_source_kernels_are_timed_when_profiling(dp, pooley):
+    """Run-time compiled kernels go through the module-launch path; with profiling on they are launched with start/stop
+    events (hipExtModuleLaunchKernel) and must give the same results and appear in the statistics."""
+    pf = dp.ParticleFilter(_model(dp), pooley)
+    theta = np.array([[0.003], [0.1], [0.01], [0.02]])
+    plain = {P: pf.loglik(theta, P, seed=3)[0] for P in (200, 5000)}   # whole-filter kernel, multi-kernel path
+    pf.set_profiling(True)
+    timed = {P: pf.loglik(theta, P, seed=3)[0] for P in (200, 5000)}
+    st = pf.kernel_stats()
+    pf.set_profiling(False)
+    assert timed == plain
+    assert st["k_filter_small"][0] == 1 and st["k_filter_small"][1] > 0.0
+    assert st["k_propagate"][0] == pf.n_obs and st["k_propagate"][1] > 0.0
+    pf.close()
