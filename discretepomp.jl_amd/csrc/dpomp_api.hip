@@ -200,6 +200,21 @@ int fail(dpomp_handle* h, int code, const char* fmt, ...) {
                         #expr, hipGetErrorString(e_));                                         \
     } while (0)
 
+// Device scratch of one API call: freed when the call returns, early error returns of HIPCHK included.
+struct DeviceScratch {
+    std::vector<void*> owned;
+    ~DeviceScratch() {
+        for (void* p : owned) (void)hipFree(p);
+    }
+    hipError_t doubles(double** out, size_t n) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, n * sizeof(double));
+        if (e == hipSuccess) owned.push_back(p);
+        *out = static_cast<double*>(p);
+        return e;
+    }
+};
+
 hipEvent_t next_event(dpomp_handle* h) {
     if (h->events_used == h->event_pool.size()) {
         hipEvent_t e;
@@ -1167,11 +1182,12 @@ int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const dou
     if (!h) return DPOMP_EINVAL;
     if (n < 1) return fail(h, DPOMP_EINVAL, "n < 1");
     HIPCHK(h, hipSetDevice(h->device));
+    DeviceScratch scratch;
     double *dx = nullptr, *du = nullptr, *dl = nullptr, *de = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dx, (size_t)n * 8));
-    HIPCHK(h, hipMalloc((void**)&du, (size_t)n * 8));
-    HIPCHK(h, hipMalloc((void**)&dl, (size_t)n * 8));
-    HIPCHK(h, hipMalloc((void**)&de, (size_t)n * 8));
+    HIPCHK(h, scratch.doubles(&dx, (size_t)n));
+    HIPCHK(h, scratch.doubles(&du, (size_t)n));
+    HIPCHK(h, scratch.doubles(&dl, (size_t)n));
+    HIPCHK(h, scratch.doubles(&de, (size_t)n));
     if (x_in) HIPCHK(h, hipMemcpy(dx, x_in, (size_t)n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, seed,
                        x_in ? (const double*)dx : (const double*)nullptr, du, dl, de);
@@ -1179,10 +1195,6 @@ int dpomp_selftest_numerics(dpomp_handle* h, int64_t n, uint64_t seed, const dou
     if (out_uniform) HIPCHK(h, hipMemcpy(out_uniform, du, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (out_log && x_in) HIPCHK(h, hipMemcpy(out_log, dl, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (out_exp && x_in) HIPCHK(h, hipMemcpy(out_exp, de, (size_t)n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(dx);
-    (void)hipFree(du);
-    (void)hipFree(dl);
-    (void)hipFree(de);
     return DPOMP_OK;
 }
 
@@ -1191,15 +1203,15 @@ int dpomp_selftest_division(dpomp_handle* h, int64_t n, const double* a_in, cons
     if (!h || !a_in || !b_in || !out_fast || !out_plain) return fail(h, DPOMP_EINVAL, "null argument");
     if (n < 1) return fail(h, DPOMP_EINVAL, "n < 1");
     HIPCHK(h, hipSetDevice(h->device));
+    DeviceScratch scratch;
     double* d[4] = {nullptr, nullptr, nullptr, nullptr};
-    for (auto& p : d) HIPCHK(h, hipMalloc((void**)&p, (size_t)n * 8));
+    for (auto& p : d) HIPCHK(h, scratch.doubles(&p, (size_t)n));
     HIPCHK(h, hipMemcpy(d[0], a_in, (size_t)n * 8, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d[1], b_in, (size_t)n * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_selftest_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, d[0], d[1], d[2], d[3]);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipMemcpy(out_fast, d[2], (size_t)n * 8, hipMemcpyDeviceToHost));
     HIPCHK(h, hipMemcpy(out_plain, d[3], (size_t)n * 8, hipMemcpyDeviceToHost));
-    for (auto& p : d) (void)hipFree(p);
     return DPOMP_OK;
 }
 
