@@ -1,0 +1,52 @@
+"""One-off fuzz campaign: many random rate-table models (tests/test_random_models.py's generator) through the GPU
+filter with random schedules and sizes, each compared bit for bit with the oracle.
+
+    N=400 python tools/fuzz_random_models.py      # on the GPU box
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dpomp_amd as dp  # noqa: E402
+from oracle import oracle as orc  # noqa: E402  (checker)
+from test_random_models import random_model  # noqa: E402
+
+
+def main():
+    n_models = int(os.environ.get("N", "400"))
+    bad, inf, capped = [], 0, 0
+    for seed in range(n_models):
+        rng = np.random.default_rng(50000 + seed)
+        model, theta = random_model(dp, rng)
+        model.max_events_per_interval = 5000
+        y = [dp.Observation(t, int(rng.random() < 0.85), 1.0, [int(rng.integers(5, 60))]) for t in (1.0, 2.5, 4.0, 4.0 + float(rng.random()))]
+        pf = dp.ParticleFilter(model, y)
+        variant = int(rng.choice([0, 1, 2, 4, 16, 32]))
+        pf.set_propagate_variant(variant)
+        P = int(rng.integers(2, 3000))
+        rs = int(rng.choice([1, 1, 2, 3]))
+        pf.set_resampler(rs)
+        pop = pf.alloc_population(2, P)
+        th2 = np.stack([theta, theta * 1.3], axis=1)
+        ll = pf.partial_log_likelihood(pop, th2, 1, len(y), seed=seed, seg_base=3)
+        for b in range(2):
+            ref = orc.pf_loglik(pf.desc, P, th2[:, b], seed=seed, seg=3 + b, rs_type=rs)
+            same = (np.array_equal(pop.download(b), ref.pop) and pf.last_status[b] == ref.status
+                    and ((ll[b] == ref.ll) or (np.isinf(ll[b]) and np.isinf(ref.ll))))
+            if not same:
+                bad.append({"seed": seed, "b": b, "variant": variant, "P": P, "rs": rs, "gpu": float(ll[b]), "oracle": ref.ll})
+            inf += int(np.isinf(ref.ll))
+            capped += int(ref.status & 1)
+        pf.close()
+    print(json.dumps({"models": n_models, "filters": 2 * n_models, "mismatches": bad, "minus_inf_results": inf,
+                      "event_cap_hits": capped}))
+    assert not bad
+
+
+if __name__ == "__main__":
+    main()
