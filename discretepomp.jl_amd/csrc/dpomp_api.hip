@@ -716,8 +716,9 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
         return DPOMP_EDEVICE;
     }
     for (const char* n : kRtcNames) api->add_name(prog, n);
-    const char* opts[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17"};
-    const hiprtcResult r = api->compile(prog, 4, opts);
+    const char* opts[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
+                          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
+    const hiprtcResult r = api->compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     size_t ls = 0;
     if (api->log_size && api->log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         log.resize(ls);
