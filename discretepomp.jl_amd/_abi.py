@@ -29,6 +29,8 @@ RS_SYSTEMATIC, RS_STRATIFIED, RS_MULTINOMIAL = 1, 2, 3
  BUILTIN_SEI_FD, BUILTIN_SEIR_FD, BUILTIN_LOTKA, BUILTIN_ROSSMAC) = range(11)
 BUILTIN_USER = 100
 DBG_LOGW, DBG_OFFSPRING_END = 1, 2
+STATIC_MAX_BYTES = 16 << 20
+STATIC_MAX_SEGMENTS = 4096
 
 
 class RateTermC(C.Structure):
@@ -87,6 +89,8 @@ _PROTOTYPES = {
     "dpomp_set_propagate_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "dpomp_pf_loglik": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
                                   C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "dpomp_pf_loglik_static": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
+                                         C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "dpomp_pop_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "dpomp_pop_free": (None, [C.c_void_p, C.c_void_p]),
     "dpomp_pf_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,

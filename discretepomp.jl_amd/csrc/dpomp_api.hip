@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -102,7 +103,19 @@ struct PendingTiming {
     hipEvent_t e0, e1;
 };
 
+// Static device memory of dpomp_pf_loglik_static: every working buffer of a filter call (both state buffers,
+// log-weights, offspring boundaries, tile sums, control block, parameters) carved from one file-scope array, so that
+// entry point calls no allocator.  Each GPU the library runs on holds its own copy of the array at its own address
+// until the process ends; host code must never pass the array's NAME to a kernel or a copy (on the host it is a
+// stand-in, not a device address) -- only the per-device pointer obtained once with hipGetSymbolAddress.
+constexpr size_t kStaticScratchBytes = DPOMP_STATIC_MAX_BYTES;
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_dev[kMaxDevices] = {};  // [device] device address of `scratch` on that GPU
+
 }  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 struct dpomp_handle {
     int device = 0;
@@ -144,6 +157,9 @@ struct dpomp_handle {
     std::string err;
     // scratch for dpomp_pf_loglik
     dpomp_pop* scratch_pop = nullptr;
+    // pinned staging of dpomp_pf_loglik_static (allocated at create: that entry point allocates nothing)
+    char* static_h_result = nullptr;
+    double* static_h_theta = nullptr;
 };
 
 struct dpomp_pop {
@@ -178,6 +194,7 @@ struct dpomp_pop {
     int64_t* ancestors = nullptr;          // [B]
     bool initialised = false;
     int last_weighted_obs = -1;
+    bool static_mem = false;  // buffers carved from the library's static device array: nothing to allocate or free
 };
 
 namespace {
@@ -321,6 +338,7 @@ int validate_desc(const dpomp_model_desc* d) {
 
 void pop_release(dpomp_pop* p) {
     if (!p) return;
+    if (p->static_mem) return;  // a view of the static device array on the caller's stack: nothing is owned
     for (int i = 0; i < 2; ++i) (void)hipFree(p->state[i]);
     (void)hipFree(p->logw);
     (void)hipFree(p->offs);
@@ -345,11 +363,11 @@ void pop_release(dpomp_pop* p) {
     delete p;
 }
 
-int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
-    if (B < 1 || P < 1 || P >= ((int64_t)1 << 31) - kTile) return fail(h, DPOMP_EINVAL, "B=%lld P=%lld out of range", (long long)B, (long long)P);
-    if (B > 65535) return fail(h, DPOMP_EINVAL, "B=%lld exceeds 65535 segments per call", (long long)B);
-    HIPCHK(h, hipSetDevice(h->device));
-    dpomp_pop* p = new dpomp_pop;
+// Shape of a population and of its control block:
+// [ll B f64][events u64][status B u32, padded to 8 B][per-interval counters][segmax T*B u64] -> one clear and one
+// result download per call.  Per observation interval: executed events and 64 * sum of per-wave maxima, as partial
+// sums on 128-byte lines of their own (dpomp_kernels.h: sched_add).
+void pop_set_shape(dpomp_handle* h, dpomp_pop* p, int64_t B, int64_t P) {
     p->B = B;
     p->P = P;
     p->Pp = (P + kTile - 1) / kTile * kTile;
@@ -357,6 +375,31 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     p->S = h->dm.S;
     p->K = h->dm.K;
     p->T = h->T;
+    const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
+    const size_t n_sc = (size_t)p->T * kSchedStride * 8;
+    p->sched_offset = n_ll + n_ev + n_st;
+    p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
+    p->ctl_bytes = p->ctl_result_bytes + n_sm;
+}
+void pop_bind_ctl(dpomp_pop* p) {
+    const size_t n_ll = (size_t)p->B * 8, n_ev = 8;
+    p->ll = reinterpret_cast<double*>(p->ctl);
+    p->events = reinterpret_cast<unsigned long long*>(p->ctl + n_ll);
+    p->status = reinterpret_cast<uint32_t*>(p->ctl + n_ll + n_ev);
+    p->segmax = reinterpret_cast<unsigned long long*>(p->ctl + p->ctl_result_bytes);
+}
+
+int check_pop_dims(dpomp_handle* h, int64_t B, int64_t P) {
+    if (B < 1 || P < 1 || P >= ((int64_t)1 << 31) - kTile) return fail(h, DPOMP_EINVAL, "B=%lld P=%lld out of range", (long long)B, (long long)P);
+    if (B > 65535) return fail(h, DPOMP_EINVAL, "B=%lld exceeds 65535 segments per call", (long long)B);
+    return DPOMP_OK;
+}
+
+int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
+    if (int rc = check_pop_dims(h, B, P)) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    dpomp_pop* p = new dpomp_pop;
+    pop_set_shape(h, p, B, P);
     const size_t n_state = (size_t)B * p->S * p->Pp;
 #define DPOMP_ALLOC(ptr, bytes)                                                    \
     do {                                                                           \
@@ -374,22 +417,8 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->tile_end, (size_t)B * p->nblk * 4);
     DPOMP_ALLOC(p->rsu, (size_t)B * 8);
-    // one control block: [ll B f64][events u64][status B u32, padded to 8 B][segmax T*B u64] -> one memset and one
-    // result download per call
-    {
-        const size_t n_ll = (size_t)B * 8, n_ev = 8, n_st = ((size_t)B * 4 + 7) / 8 * 8, n_sm = (size_t)p->T * B * 8;
-        // per observation: executed events and 64 * sum of per-wave maxima, as partial sums on 128-byte lines of their
-        // own (dpomp_kernels.h: sched_add)
-        const size_t n_sc = (size_t)p->T * kSchedStride * 8;
-        p->sched_offset = n_ll + n_ev + n_st;
-        p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
-        p->ctl_bytes = p->ctl_result_bytes + n_sm;
-        DPOMP_ALLOC(p->ctl, p->ctl_bytes);
-        p->ll = reinterpret_cast<double*>(p->ctl);
-        p->events = reinterpret_cast<unsigned long long*>(p->ctl + n_ll);
-        p->status = reinterpret_cast<uint32_t*>(p->ctl + n_ll + n_ev);
-        p->segmax = reinterpret_cast<unsigned long long*>(p->ctl + p->ctl_result_bytes);
-    }
+    DPOMP_ALLOC(p->ctl, p->ctl_bytes);
+    pop_bind_ctl(p);
     DPOMP_ALLOC(p->wtot, (size_t)B * 8);
     DPOMP_ALLOC(p->theta, (size_t)B * p->K * 8);
     DPOMP_ALLOC(p->ancestors, (size_t)B * 8);
@@ -401,6 +430,87 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     }
     *out = p;
     return DPOMP_OK;
+}
+
+// The same buffers carved out of one block of device memory starting at `base` (256-byte aligned pieces), for the
+// resampler and the ESS mode the handle is set to.  Returns the bytes used; with base == nullptr only the size is
+// computed (the pointers written are then meaningless offsets).
+size_t pop_carve(dpomp_handle* h, dpomp_pop* p, unsigned char* base) {
+    size_t used = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* r = reinterpret_cast<unsigned char*>(reinterpret_cast<uintptr_t>(base) + used);
+        used += (bytes + 255) / 256 * 256;
+        return r;
+    };
+    const size_t B = (size_t)p->B, n_state = B * p->S * p->Pp;
+    p->state[0] = reinterpret_cast<int32_t*>(take(n_state * 4));
+    p->state[1] = reinterpret_cast<int32_t*>(take(n_state * 4));
+    p->logw = reinterpret_cast<double*>(take(B * p->Pp * 8));
+    p->offs = reinterpret_cast<int32_t*>(take(B * p->Pp * 4));
+    p->blocksum = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
+    p->blockprefix = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
+    p->tile_end = reinterpret_cast<int32_t*>(take(B * p->nblk * 4));
+    p->rsu = reinterpret_cast<double*>(take(B * 8));
+    p->ctl = reinterpret_cast<char*>(take(p->ctl_bytes));
+    p->wtot = reinterpret_cast<unsigned long long*>(take(B * 8));
+    p->theta = reinterpret_cast<double*>(take(B * p->K * 8));
+    if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
+        p->posw = reinterpret_cast<double*>(take(B * p->Pp * 8));
+        p->tile_end_pos = reinterpret_cast<double*>(take(B * p->nblk * 8));
+    }
+    if (h->ess_frac > 0.0) {
+        p->blocksum2 = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 16));
+        for (int i = 0; i < 2; ++i) {
+            p->carry[i] = reinterpret_cast<int32_t*>(take(B * 4));
+            p->lprev[i] = reinterpret_cast<double*>(take(B * 8));
+        }
+        p->noresample = reinterpret_cast<int32_t*>(take(B * 4));
+    }
+    return used;
+}
+
+// Lazily allocated groups of a population (resamplers 2/3, ESS mode): allocated into locals and committed together,
+// so a failure half way leaves the population as it was.
+int pop_ensure_pos(dpomp_handle* h, dpomp_pop* p) {
+    if (p->posw) return DPOMP_OK;
+    if (p->static_mem) return fail(h, DPOMP_ESTATE, "static population was carved without the stratified/multinomial buffers");
+    double *a = nullptr, *b = nullptr;
+    if (hipMalloc((void**)&a, (size_t)p->B * p->Pp * 8) != hipSuccess || hipMalloc((void**)&b, (size_t)p->B * p->nblk * 8) != hipSuccess) {
+        (void)hipFree(a);
+        (void)hipFree(b);
+        return fail(h, DPOMP_ENOMEM, "hipMalloc of the scaled cumulative weights failed");
+    }
+    p->posw = a;
+    p->tile_end_pos = b;
+    return DPOMP_OK;
+}
+int pop_ensure_adaptive(dpomp_handle* h, dpomp_pop* p) {
+    if (p->blocksum2) return DPOMP_OK;
+    if (p->static_mem) return fail(h, DPOMP_ESTATE, "static population was carved without the ESS buffers");
+    void* q[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t B = (size_t)p->B;
+    const size_t bytes[6] = {B * p->nblk * 16, B * 4, B * 4, B * 8, B * 8, B * 4};
+    for (int i = 0; i < 6; ++i)
+        if (hipMalloc(&q[i], bytes[i]) != hipSuccess) {
+            for (int j = 0; j < 6; ++j) (void)hipFree(q[j]);
+            return fail(h, DPOMP_ENOMEM, "hipMalloc of the ESS-adaptive buffers failed");
+        }
+    p->blocksum2 = static_cast<unsigned long long*>(q[0]);
+    p->carry[0] = static_cast<int32_t*>(q[1]);
+    p->carry[1] = static_cast<int32_t*>(q[2]);
+    p->lprev[0] = static_cast<double*>(q[3]);
+    p->lprev[1] = static_cast<double*>(q[4]);
+    p->noresample = static_cast<int32_t*>(q[5]);
+    return DPOMP_OK;
+}
+
+// Clears device memory with a kernel instead of hipMemsetAsync (the call may sit on a stream that is being captured,
+// and memset nodes of a captured graph have replayed wrongly).  bytes is a multiple of 4.
+hipError_t clear_device(hipStream_t st, void* ptr, size_t bytes) {
+    const size_t words = bytes / 4;
+    if (!words) return hipSuccess;
+    hipLaunchKernelGGL(k_zero, dim3((unsigned)((words + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, static_cast<uint32_t*>(ptr), (int64_t)words);
+    return hipGetLastError();
 }
 
 hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a);
@@ -415,33 +525,29 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (ymin > 1 && !p->initialised) return fail(h, DPOMP_ESTATE, "ymin=%d on a population that was never initialised (call with ymin=1 or upload first)", ymin);
     if (seg_base < 0 || seg_base + p->B > 0xFFFFFFFFll) return fail(h, DPOMP_EINVAL, "seg_base out of range");
     HIPCHK(h, hipSetDevice(h->device));
+    if (p->T != T || p->S != h->dm.S || p->K != h->dm.K)
+        return fail(h, DPOMP_EINVAL, "population belongs to another filter (T/S/K = %d/%d/%d, this handle %d/%d/%d)", p->T, p->S, p->K, T, h->dm.S, h->dm.K);
     if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
         if (p->nblk > kGatherPosMaxTiles) return fail(h, DPOMP_EINVAL, "resampler %d supports at most %d particles per filter", h->rs_type, kGatherPosMaxTiles * kTile);
-        if (!p->posw) {
-            HIPCHK(h, hipMalloc((void**)&p->posw, (size_t)p->B * p->Pp * 8));
-            HIPCHK(h, hipMalloc((void**)&p->tile_end_pos, (size_t)p->B * p->nblk * 8));
-        }
+        if (int rc = pop_ensure_pos(h, p)) return rc;
     }
     hipStream_t st = h->stream;
     const int64_t B = p->B;
     const dim3 block(kBlock);
     const dim3 grid_tiles((unsigned)p->nblk, (unsigned)B);
-    begin_profiled_call(h);
+    if (p->static_mem) h->profiling = false;  // (timing brackets create events on demand)
+    else begin_profiled_call(h);
 
     const bool adaptive = h->ess_frac > 0.0 && domain == DOMAIN_PROPAGATE;
-    if (adaptive && !p->blocksum2) {
-        HIPCHK(h, hipMalloc((void**)&p->blocksum2, (size_t)B * p->nblk * 16));
-        for (int i = 0; i < 2; ++i) {
-            HIPCHK(h, hipMalloc((void**)&p->carry[i], (size_t)B * 4));
-            HIPCHK(h, hipMalloc((void**)&p->lprev[i], (size_t)B * 8));
-            HIPCHK(h, hipMemsetAsync(p->carry[i], 0, (size_t)B * 4, st));
-        }
-        HIPCHK(h, hipMalloc((void**)&p->noresample, (size_t)B * 4));
+    if (adaptive) {
+        const bool fresh = !p->blocksum2;
+        if (int rc = pop_ensure_adaptive(h, p)) return rc;
+        if (fresh || ymin == 1) HIPCHK(h, clear_device(st, p->carry[p->carry_cur], (size_t)B * 4));
+        if (fresh) HIPCHK(h, clear_device(st, p->carry[p->carry_cur ^ 1], (size_t)B * 4));
     }
-    if (adaptive && ymin == 1) HIPCHK(h, hipMemsetAsync(p->carry[p->carry_cur], 0, (size_t)B * 4, st));
     memcpy(p->h_theta, theta, (size_t)B * p->K * 8);
     HIPCHK(h, hipMemcpyAsync(p->theta, p->h_theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemsetAsync(p->ctl, 0, p->ctl_bytes, st));
+    HIPCHK(h, clear_device(st, p->ctl, p->ctl_bytes));
 
     // A filter that fits one workgroup runs whole in ONE kernel (all observations ymin..ymax, everything between
     // the steps kept in LDS / registers) -- the regime of the reference's defaults (200 particles per filter).
@@ -826,6 +932,29 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         return rc;
     }
     h->stream = h->own_stream;
+    {   // device address of the static scratch array on THIS GPU (each device holds its own copy), once per device
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (device < kMaxDevices && !g_scratch_dev[device]) {
+            unsigned char* ptr = nullptr;
+            e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) {
+                rc = fail(nullptr, DPOMP_EDEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString(e));
+                (void)hipStreamDestroy(h->own_stream);
+                delete h;
+                return rc;
+            }
+            g_scratch_dev[device] = ptr;
+        }
+    }
+    {   // pinned staging of dpomp_pf_loglik_static, sized for its largest call
+        const size_t n_res = (size_t)DPOMP_STATIC_MAX_SEGMENTS * 12 + 16 + (size_t)d->n_obs * kSchedStride * 8;
+        if (hipHostMalloc((void**)&h->static_h_result, n_res, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&h->static_h_theta, (size_t)DPOMP_STATIC_MAX_SEGMENTS * DPOMP_MAX_PARAMS * 8, hipHostMallocDefault) != hipSuccess) {
+            rc = fail(nullptr, DPOMP_ENOMEM, "hipHostMalloc of the static staging buffers failed");
+            dpomp_destroy(h);
+            return rc;
+        }
+    }
     h->T = d->n_obs;
     h->lane_util.assign((size_t)d->n_obs, -1.0);
     h->obs_time.assign(d->obs_time, d->obs_time + d->n_obs);
@@ -925,6 +1054,8 @@ void dpomp_destroy(dpomp_handle* h) {
     (void)hipFree(h->d_obs_id);
     (void)hipFree(h->d_obs_val);
     if (h->scratch_pop) pop_release(h->scratch_pop);
+    (void)hipHostFree(h->static_h_result);
+    (void)hipHostFree(h->static_h_theta);
     for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -993,9 +1124,33 @@ int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, 
     return run_partial(h, h->scratch_pop, theta, 1, h->T, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
 }
 
+int dpomp_pf_loglik_static(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
+                           int64_t seg_base, double* out_ll, uint32_t* out_status) {
+    if (!h) return DPOMP_EINVAL;
+    if (!out_ll) return fail(h, DPOMP_EINVAL, "out_ll is NULL");
+    if (int rc = check_pop_dims(h, B, P)) return rc;
+    if (B > DPOMP_STATIC_MAX_SEGMENTS)
+        return fail(h, DPOMP_EINVAL, "dpomp_pf_loglik_static: B=%lld exceeds its maximum of %d filters per call", (long long)B, DPOMP_STATIC_MAX_SEGMENTS);
+    unsigned char* const base = h->device < kMaxDevices ? g_scratch_dev[h->device] : nullptr;
+    if (!base) return fail(h, DPOMP_ESTATE, "no static scratch memory on device %d", h->device);
+    dpomp_pop view;  // on the stack: a view of the static array, owns nothing
+    view.static_mem = true;
+    pop_set_shape(h, &view, B, P);
+    const size_t need = pop_carve(h, &view, nullptr);
+    if (need > kStaticScratchBytes)
+        return fail(h, DPOMP_EINVAL, "dpomp_pf_loglik_static: B=%lld x P=%lld needs %zu bytes of working memory, the static scratch array holds %zu "
+                    "(use dpomp_pf_loglik, which allocates)", (long long)B, (long long)P, need, kStaticScratchBytes);
+    pop_carve(h, &view, base);
+    pop_bind_ctl(&view);
+    view.h_result = h->static_h_result;
+    view.h_theta = h->static_h_theta;
+    return run_partial(h, &view, theta, 1, h->T, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
+}
+
 int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
     if (!h) return DPOMP_EINVAL;
     if (!p || !ancestors) return fail(h, DPOMP_EINVAL, "pop or ancestors is NULL");
+    if (p->T != h->T || p->S != h->dm.S || p->K != h->dm.K) return fail(h, DPOMP_EINVAL, "population belongs to another filter");
     for (int64_t b = 0; b < p->B; ++b)
         if (ancestors[b] < 0 || ancestors[b] >= p->B) return fail(h, DPOMP_EINVAL, "ancestors[%lld]=%lld out of range", (long long)b, (long long)ancestors[b]);
     HIPCHK(h, hipSetDevice(h->device));
@@ -1016,6 +1171,7 @@ int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const 
     if (!h) return DPOMP_EINVAL;
     if (!dst || !src || !take || dst == src) return fail(h, DPOMP_EINVAL, "dst/src/take invalid");
     if (dst->P != src->P || dst->S != src->S) return fail(h, DPOMP_EINVAL, "populations differ in shape");
+    if (dst->T != h->T || dst->S != h->dm.S || dst->K != h->dm.K) return fail(h, DPOMP_EINVAL, "population belongs to another filter");
     bool any = false;
     for (int64_t b = 0; b < dst->B; ++b) {
         if (take[b] >= src->B) return fail(h, DPOMP_EINVAL, "take[%lld]=%lld out of range", (long long)b, (long long)take[b]);

@@ -355,6 +355,12 @@ __device__ __forceinline__ bool stopped_on_cap(int n, int cap) { return n >= cap
 // after a FAST loop returned false: neither the cap nor the clock stopped the particle, so its rate total did
 __device__ __forceinline__ bool stopped_on_range(int n, int cap, double time, double tmax) { return n < cap && !(time > tmax); }
 
+// ---- k_zero: clears counters, flags and the control block (in place of hipMemsetAsync) -------------------
+__global__ __launch_bounds__(kBlock) void k_zero(uint32_t* dst, int64_t words) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < words) dst[i] = 0u;
+}
+
 // ---- k_init: pop[i,:] .= initial_condition   (hmm_particle_filter.jl:42-44) -----------------
 __global__ __launch_bounds__(kBlock) void k_init(DevModel m, int32_t* state, int64_t Pp) {
     const int64_t b = blockIdx.y;

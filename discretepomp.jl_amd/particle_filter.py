@@ -193,6 +193,19 @@ class ParticleFilter:
         self.last_status = status
         return out
 
+    def loglik_static(self, theta, np_particles: int = C_DF_PF_P, seed: int = 1, seg_base: int = 0) -> np.ndarray:
+        """:meth:`loglik` through ``dpomp_pf_loglik_static``: same results, but the call allocates no device
+        memory (working buffers live in the library's static device array; for callers that must not allocate).
+        Raises :class:`DpompError` when the call does not fit that array."""
+        th = self._theta_matrix(theta)
+        B = th.shape[0]
+        out = np.empty(B, dtype=np.float64)
+        status = np.zeros(B, dtype=np.uint32)
+        self._check(self._lib.dpomp_pf_loglik_static(self._h, _dptr(th), B, int(np_particles), int(seed) & (2**64 - 1),
+                                                     int(seg_base), _dptr(out), status.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.last_status = status
+        return out
+
     def alloc_population(self, B: int, np_particles: int) -> Population:
         return Population(self, B, np_particles)
 

@@ -190,6 +190,20 @@ int dpomp_set_propagate_variant(dpomp_handle* h, int variant);
 int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
                     int64_t seg_base, double* out_ll, uint32_t* out_status);
 
+/* dpomp_pf_loglik for callers that cannot allocate device memory.  It has NO counterpart in the reference: it exists
+ * for callers that must not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation.  Same arguments, same results bit for bit as dpomp_pf_loglik (whatever resampler / ESS threshold the
+ * handle is set to), but every working buffer of the call lives in one static device array of
+ * DPOMP_STATIC_MAX_BYTES that each GPU the library runs on holds until the process ends; the call performs no
+ * hipMalloc / hipFree / hipHostMalloc / event creation (per-kernel profiling is off for it).  Calls whose working set
+ * (about (8 S + 12) bytes per particle, plus 20 with resamplers 2/3) exceeds the array, or with
+ * B > DPOMP_STATIC_MAX_SEGMENTS, are rejected with DPOMP_EINVAL.  All calls on one GPU share that GPU's array, from
+ * every handle and thread: calls that overlap on one GPU race -- serialise them. */
+#define DPOMP_STATIC_MAX_BYTES (16u << 20)
+#define DPOMP_STATIC_MAX_SEGMENTS 4096
+int dpomp_pf_loglik_static(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
+                           int64_t seg_base, double* out_ll, uint32_t* out_status);
+
 /* Device-resident populations for the incremental form. */
 int dpomp_pop_alloc(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out);
 void dpomp_pop_free(dpomp_handle* h, dpomp_pop* pop);
