@@ -70,13 +70,17 @@ def cpu_baseline(dp, P_serial, P_parallel):
     t0 = time.perf_counter()
     r1 = orc.pf_loglik(desc, P_serial, THETA, seed=1, nthreads=1)
     t_serial = time.perf_counter() - t0
-    cores = max(1, min(os.cpu_count() or 1, orc.max_threads()))
+    # Every core this job may use: the scheduler affinity of the process, capped by what the OpenMP runtime was told
+    # (OMP_NUM_THREADS, which a shared GPU box sets to its per-GPU CPU share).  All three figures go into the line.
+    host_cpus = os.cpu_count() or 1
     try:
-        cores = min(cores, len(os.sched_getaffinity(0)))
+        affinity = len(os.sched_getaffinity(0))
     except AttributeError:
-        pass
-    # one GPU's share of the host (an 8-GPU MI355X node has 128 cores / 256 threads): 16 threads by default
-    cores = max(1, min(cores, int(os.environ.get("DPOMP_CPU_THREADS", "16"))))
+        affinity = host_cpus
+    omp_max = orc.max_threads()
+    cores = max(1, min(affinity, omp_max))
+    if os.environ.get("DPOMP_CPU_THREADS"):
+        cores = max(1, int(os.environ["DPOMP_CPU_THREADS"]))
     orc.pf_loglik(desc, 4096, THETA, seed=2, nthreads=cores)  # spin the thread pool up
     t0 = time.perf_counter()
     rp = orc.pf_loglik(desc, P_parallel, THETA, seed=1, nthreads=cores)
@@ -86,9 +90,13 @@ def cpu_baseline(dp, P_serial, P_parallel):
         "value": P_parallel * T / t_par,
         "unit": "particle-steps/s",
         "cores": cores,
+        "host_cpu_count": host_cpus,
+        "affinity_cpus": affinity,
+        "omp_max_threads": omp_max,
         "kind": "port",
         "sample": f"oracle C restatement (reference is Julia, absent here); full Pooley SIS PF, "
-                  f"{P_parallel} particles on {cores} OpenMP threads ({t_par:.2f} s); serial run "
+                  f"{P_parallel} particles on {cores} OpenMP threads = min(affinity {affinity}, OMP max threads {omp_max}) "
+                  f"of a host with {host_cpus} logical CPUs ({t_par:.2f} s); serial run "
                   f"{P_serial} particles ({t_serial:.2f} s)",
         "serial_value": P_serial * T / t_serial,
         "serial_events_per_s": r1.events / t_serial,
@@ -97,6 +105,51 @@ def cpu_baseline(dp, P_serial, P_parallel):
         "note": "the restatement does not heap-allocate per event as the Julia code does "
                 "(src/hmm_examples.jl:12-14): it is faster than the real reference, so GPU/CPU ratios are conservative",
     }
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` started as a plain process: start N ranks (one per GPU) with torch.distributed.run as a
+    CHILD process -- this process has not touched the GPU and never does -- and exit with its code."""
+    import subprocess
+    if not args.dry_run:
+        import torch
+        n = torch.cuda.device_count()  # counts devices without initialising the GPU
+        if n < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} GPU(s) visible")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launch plumbing only (CPU test of `--gpus N`): rendezvous over gloo, the same rank accounting as the real
+    run, NO filter -- the line says so and carries no value."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ranks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64))
+        seen = sorted(int(r[0]) for r in ranks)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = [0]
+    if seen != list(range(world)):
+        raise SystemExit(f"rank accounting broken: {seen}")
+    if rank == 0:
+        print(json.dumps({"metric": "particle-steps/sec", "value": None, "unit": "particle-steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": seen}))
 
 
 def main():
@@ -111,24 +164,41 @@ def main():
     ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="HIP-event brackets around the kernels of every n-th timed step (the markers cost GPU time)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch plumbing only (gloo rendezvous, rank accounting, no GPU, no filter): for the CPU test of --gpus N")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python bench.py --gpus N`: become the launcher
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the particle filter has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # n_gpus is only claimed if `world` distinct ranks sit on `world` distinct devices of this node
+        me = torch.tensor([rank, local_rank], dtype=torch.int64, device="cuda")
+        everyone = torch.zeros((world, 2), dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(everyone, me)
+        everyone = everyone.cpu().numpy()
+        if sorted(everyone[:, 0].tolist()) != list(range(world)) or len(set(everyone[:, 1].tolist())) != world:
+            raise SystemExit(f"--gpus {world}: ranks/devices seen {everyone.tolist()} are not {world} distinct GPUs")
 
     import dpomp_amd as dp
 

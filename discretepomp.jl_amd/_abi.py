@@ -91,6 +91,7 @@ _PROTOTYPES = {
                                   C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "dpomp_pf_loglik_static": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
                                          C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "dpomp_abi_sizeof": (C.c_int, [C.c_int]),
     "dpomp_pop_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "dpomp_pop_free": (None, [C.c_void_p, C.c_void_p]),
     "dpomp_pf_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,

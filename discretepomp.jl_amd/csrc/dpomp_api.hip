@@ -1147,6 +1147,15 @@ int dpomp_pf_loglik_static(dpomp_handle* h, const double* theta, int64_t B, int6
     return run_partial(h, &view, theta, 1, h->T, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
 }
 
+int dpomp_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(dpomp_model_desc);
+        case 1: return (int)sizeof(dpomp_rate_term);
+        case 2: return (int)sizeof(dpomp_obs_model);
+        default: return -1;
+    }
+}
+
 int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* p, const int64_t* ancestors) {
     if (!h) return DPOMP_EINVAL;
     if (!p || !ancestors) return fail(h, DPOMP_EINVAL, "pop or ancestors is NULL");

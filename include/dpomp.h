@@ -145,6 +145,9 @@ typedef struct dpomp_pop dpomp_pop;
 
 /* ---- lifecycle ---------------------------------------------------------------- */
 int dpomp_device_count(void);
+/* sizeof of the structs that cross the boundary (0 dpomp_model_desc, 1 dpomp_rate_term, 2 dpomp_obs_model; -1 for
+ * anything else), so a binding in another language can assert its own layout at load time. */
+int dpomp_abi_sizeof(int which);
 const char* dpomp_version(void);
 const char* dpomp_last_global_error(void);
 
