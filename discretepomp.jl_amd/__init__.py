@@ -14,7 +14,7 @@ from .pmcmc import MCMCSample, RejectionSample, gelman_sre, handle_rej_samples, 
 from .sim import Event, Particle, SimResults, generate_observations, gillespie_sim, save_to_file
 from .arq import ARQMCMCSample, ARQModel, GridPoint, run_arq_mcmc_analysis, run_inner_mcmc_analysis
 from . import parallel  # noqa: F401
-from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, ParticleFilter, Population, check_rate_source,
+from .particle_filter import (C_DF_ESS_CRIT, C_DF_PF_P, DpompError, EventCapWarning, ParticleFilter, Population, check_rate_source,
                               get_particle_filter_lpdf)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

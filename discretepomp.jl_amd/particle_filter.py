@@ -10,6 +10,8 @@ All arithmetic happens in libdpomp_hip.so on the GPU; this module only marshals 
 from __future__ import annotations
 
 import ctypes as C
+import warnings
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -20,6 +22,11 @@ from .model import DPOMPModel, ModelDescriptor, Observation
 # defaults of the reference (src/DiscretePOMP.jl:50-52)
 C_DF_PF_P = 200
 C_DF_ESS_CRIT = 0.3
+
+
+class EventCapWarning(RuntimeWarning):
+    """A particle reached ``max_events_per_interval``: its weight was zeroed, which the reference never does (its
+    filter has no cap and would keep looping), so the returned log-likelihood is biased for those filters."""
 
 
 class DpompError(RuntimeError):
@@ -41,6 +48,7 @@ class Population:
         self.B, self.P = int(B), int(P)
         self._ptr = C.c_void_p()
         pf._check(pf._lib.dpomp_pop_alloc(pf._h, self.B, self.P, C.byref(self._ptr)))
+        pf._pops.add(self)
 
     def close(self):
         if self._ptr and self._pf._h:
@@ -117,7 +125,8 @@ class ParticleFilter:
     """A model + data set bound to one GPU (``get_private_model``, src/DiscretePOMP.jl:96-99)."""
 
     def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], device: int = 0, rs_type: int = 1,
-                 essc: float = C_DF_ESS_CRIT, force_generic: bool = False, ess_adaptive: bool = False):
+                 essc: float = C_DF_ESS_CRIT, force_generic: bool = False, ess_adaptive: bool = False,
+                 on_event_cap: str = "warn"):
         self._lib = _abi.load_library()
         self._h = C.c_void_p()
         self.device = int(device)
@@ -135,7 +144,13 @@ class ParticleFilter:
             raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
         self.rs_type = rs_type
         self._check(self._lib.dpomp_set_resampler(self._h, int(rs_type)))
+        self._pops = weakref.WeakSet()  # live populations: freed with the handle if the caller did not
+        self.ess_frac = 0.0
         self.last_status: Optional[np.ndarray] = None
+        self.status_accum = 0  # OR of the status words of every filter call on this handle (drivers report it)
+        if on_event_cap not in ("warn", "raise", "ignore"):
+            raise ValueError("on_event_cap must be 'warn', 'raise' or 'ignore'")
+        self.on_event_cap = on_event_cap
         if ess_adaptive:  # opt-in: make `essc` do what its name says
             self.set_ess_threshold(essc)
 
@@ -146,6 +161,8 @@ class ParticleFilter:
 
     def close(self):
         if self._h:
+            for pop in list(self._pops):
+                pop.close()
             self._lib.dpomp_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -154,6 +171,20 @@ class ParticleFilter:
             self.close()
         except Exception:
             pass
+
+    def _note_status(self, status: np.ndarray):
+        """Keeps the per-segment status words of the call and reacts to DPOMP_ST_EVENT_CAP: a capped particle's
+        weight is zero, so the estimate of its filter is not the reference's (states are int32 on the device,
+        values stay below 2^30 by the cap on events and the checks at create/upload)."""
+        self._note_status(status)
+        self.status_accum |= int(np.bitwise_or.reduce(status)) if status.size else 0
+        if self.on_event_cap != "ignore" and np.any(status & _abi.ST_EVENT_CAP):
+            n = int(np.count_nonzero(status & _abi.ST_EVENT_CAP))
+            msg = (f"{n} of {status.size} filters had particles stopped at max_events_per_interval "
+                   f"(weight zeroed; the reference has no such cap): their log-likelihoods are biased")
+            if self.on_event_cap == "raise":
+                raise DpompError(_abi.ESTATE, msg)
+            warnings.warn(msg, EventCapWarning, stacklevel=3)
 
     def set_stream(self, raw_stream: Optional[int]):
         """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""
@@ -167,6 +198,7 @@ class ParticleFilter:
     def set_ess_threshold(self, ess_frac: float):
         """ESS-adaptive resampling (0 = the reference's behaviour: resample at every weighted observation)."""
         self._check(self._lib.dpomp_set_ess_threshold(self._h, float(ess_frac)))
+        self.ess_frac = float(ess_frac)
 
     def set_propagate_variant(self, rpl: int):
         """Propagation-kernel variant (0 default, 1 static, 2/4 LDS queue, 16/32 compaction); never changes a result."""
@@ -190,7 +222,7 @@ class ParticleFilter:
         status = np.zeros(B, dtype=np.uint32)
         self._check(self._lib.dpomp_pf_loglik(self._h, _dptr(th), B, int(np_particles), int(seed) & (2**64 - 1),
                                               int(seg_base), _dptr(out), status.ctypes.data_as(C.POINTER(C.c_uint32))))
-        self.last_status = status
+        self._note_status(status)
         return out
 
     def loglik_static(self, theta, np_particles: int = C_DF_PF_P, seed: int = 1, seg_base: int = 0) -> np.ndarray:
@@ -203,7 +235,7 @@ class ParticleFilter:
         status = np.zeros(B, dtype=np.uint32)
         self._check(self._lib.dpomp_pf_loglik_static(self._h, _dptr(th), B, int(np_particles), int(seed) & (2**64 - 1),
                                                      int(seg_base), _dptr(out), status.ctypes.data_as(C.POINTER(C.c_uint32))))
-        self.last_status = status
+        self._note_status(status)
         return out
 
     def alloc_population(self, B: int, np_particles: int) -> Population:
@@ -221,7 +253,7 @@ class ParticleFilter:
         self._check(self._lib.dpomp_pf_partial(self._h, pop._ptr, _dptr(th), int(ymin), int(ymax),
                                                int(seed) & (2**64 - 1), int(seg_base), _dptr(out),
                                                status.ctypes.data_as(C.POINTER(C.c_uint32))))
-        self.last_status = status
+        self._note_status(status)
         return out
 
     def simulate(self, theta, n_sims: int = 1, seed: int = 1, seg_base: int = 0) -> np.ndarray:

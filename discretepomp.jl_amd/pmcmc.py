@@ -47,6 +47,7 @@ class MCMCSample:
     sre: np.ndarray          # Gelman-Rubin potential scale reduction, point estimate per parameter
     run_time: int            # ns
     acceptance_rate: np.ndarray = None  # per chain, after adaptation
+    status: int = 0          # OR of the filter status bits of every call (1 = event cap hit, 2 = all weights zero)
 
 
 def handle_rej_samples(theta: np.ndarray, ap: int = 0) -> RejectionSample:
@@ -158,6 +159,8 @@ def run_pmcmc_analysis(model, obs_data, n_chains: int = 3, initial_parameters: O
     if verbose:
         print(f"Running PMCMC analysis: {initial_parameters.shape[1]} x {steps} samples")
     try:
-        return run_pmcmc(evaluate, model.prior, initial_parameters, steps, adapt_period, seed=seed, rng=rng, verbose=verbose)
+        out = run_pmcmc(evaluate, model.prior, initial_parameters, steps, adapt_period, seed=seed, rng=rng, verbose=verbose)
+        out.status = pf.status_accum
+        return out
     finally:
         pf.close()

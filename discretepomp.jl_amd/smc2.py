@@ -20,6 +20,7 @@ proposals are drawn with the ``tj`` of its start and the accumulated factor is a
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Optional
@@ -46,6 +47,7 @@ class ImportanceSample:
     bme: np.ndarray      # [-ln evidence (standard), -ln evidence (Rao-Blackwellised)]
     acceptance_rate: float = float("nan")
     n_resample: int = 0
+    status: int = 0      # OR of the filter status bits of every call (1 = event cap hit, 2 = all weights zero)
 
 
 def compute_ess(w: np.ndarray) -> float:
@@ -99,6 +101,11 @@ class _Proposal:
         return -0.5 * np.sum(z * z, axis=0)
 
 
+def _log(x: float) -> float:
+    """Julia's log: -Inf at 0 (math.log raises there), e.g. when every incremental weight underflowed."""
+    return math.log(x) if x > 0.0 else (-math.inf if x == 0.0 else math.nan)
+
+
 def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool, alpha: float, npf: int,
               n_props: int = 1, seed: int = 1, rng: Optional[np.random.Generator] = None, verbose: bool = True,
               proposal_correction: bool = False, distributed: bool = False, group=None) -> ImportanceSample:
@@ -120,93 +127,101 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
     w = np.ones(N)
     aw = np.array([prior.logpdf(theta[:, i]) for i in range(N)])
     from .parallel import LocalBank, ShardedBank
+    if getattr(bank, "ess_frac", 0.0) > 0.0:
+        # theta-level copies (gather / take) move states only, not the log-weights an ESS-adaptive filter carries
+        raise ValueError("run_pibis needs a filter that resamples at every observation (ess_adaptive=False)")
     sb = ShardedBank(bank, N, npf, group) if distributed else LocalBank(bank, N, npf)
-    mu, cv = np.zeros(K), np.zeros((K, K))
-    k_log = [0, 0]
-    bme = np.zeros(2)
-    propd = _Proposal(K)
-    tj = 0.2
-    call = [0]
-    n_resample = 0
+    try:
+        mu, cv = np.zeros(K), np.zeros((K, K))
+        k_log = [0, 0]
+        bme = np.zeros(2)
+        propd = _Proposal(K)
+        tj = 0.2
+        call = [0]
+        n_resample = 0
 
-    def next_seed():  # every filter call gets its own stream key (the reference advances a global RNG)
-        call[0] += 1
-        return (int(seed) * 0x9E3779B97F4A7C15 + call[0]) & (2 ** 64 - 1)
+        def next_seed():  # every filter call gets its own stream key (the reference advances a global RNG)
+            call[0] += 1
+            return (int(seed) * 0x9E3779B97F4A7C15 + call[0]) & (2 ** 64 - 1)
 
-    obs_min = 1
-    for obs_i in range(1, T + 1):
-        if obs_id[obs_i - 1] <= 0:
-            continue
-        gx = sb.increment(theta, obs_min, obs_i, next_seed())  # :53-56
-        aw += gx
-        gx = np.exp(gx)
-        lml = math.log(np.sum(w * gx) / np.sum(w))  # :59
-        bme[0] += lml
-        w *= gx
+        obs_min = 1
+        for obs_i in range(1, T + 1):
+            if obs_id[obs_i - 1] <= 0:
+                continue
+            gx = sb.increment(theta, obs_min, obs_i, next_seed())  # :53-56
+            aw += gx
+            gx = np.exp(gx)
+            lml = _log(float(np.sum(w * gx) / np.sum(w)))  # :59
+            bme[0] += lml
+            w *= gx
+            mu, cv = compute_is_mu_covar(theta, w)
+            if compute_ess(w) < ess_crit:  # :65
+                n_resample += 1
+                propd.update(cv)
+                nidx = rs_systematic(w, rng)  # :70
+                theta = np.ascontiguousarray(theta[:, nidx])
+                aw = aw[nidx]
+                sb.resample(nidx)  # :74
+                mlr = float(np.mean(gx[nidx])) * (math.exp(lml) if lml > -math.inf else 0.0)
+                k_log[0] += N
+                mtd_gx = gx[nidx].copy()
+                for _ in range(n_props):  # :85
+                    centre = mu[:, None] if ind_prop else theta
+                    theta_f = propd.draw(rng, 1.0 if ind_prop else tj, centre, N)  # :87
+                    prtf = np.array([prior.logpdf(theta_f[:, p]) for p in range(N)])
+                    ok = np.isfinite(prtf)
+                    if not ok.any():
+                        continue
+                    th_run = np.where(ok[None, :], theta_f, theta)  # invalid proposals run a harmless theta, then are ignored
+                    if obs_i == 1:  # :92-94
+                        gx_f = sb.propose(th_run, 1, 1, next_seed())
+                        aw_f = gx_f.copy()
+                    else:  # :95-100
+                        aw_f = sb.propose(th_run, 1, obs_i - 1, next_seed())
+                        gx_f = sb.propose(th_run, obs_i, obs_i, next_seed())
+                        aw_f = aw_f + gx_f
+                    aw_f = aw_f + prtf
+                    log_ratio = aw_f - aw
+                    if proposal_correction and ind_prop:
+                        log_ratio = log_ratio + propd.logpdf_centred(theta - mu[:, None]) - propd.logpdf_centred(theta_f - mu[:, None])
+                    u = rng.random(N)
+                    with np.errstate(over="ignore", invalid="ignore"):
+                        accept = ok & (np.exp(log_ratio) > u)  # :104
+                    accept &= ~np.isnan(aw_f)
+                    if accept.any():
+                        mtd_gx[accept] = np.exp(gx_f[accept])
+                        theta[:, accept] = theta_f[:, accept]
+                        aw[accept] = aw_f[accept]
+                        sb.accept(accept)  # pop[p] .= pop_f  :109
+                    n_acc = int(accept.sum())
+                    k_log[1] += n_acc
+                    tj *= alpha ** n_acc * 0.999 ** int(ok.sum() - n_acc)  # :111-113, applied per sweep
+                bme[1] += _log(mlr / float(np.mean(mtd_gx))) if np.mean(mtd_gx) > 0 else math.nan  # :118
+                w[:] = 1.0
+            else:
+                bme[1] += _log(float(np.sum(w * gx) / np.sum(w)))  # :121 (with the updated w, as in the reference)
+            obs_min = obs_i + 1
         mu, cv = compute_is_mu_covar(theta, w)
-        if compute_ess(w) < ess_crit:  # :65
-            n_resample += 1
-            propd.update(cv)
-            nidx = rs_systematic(w, rng)  # :70
-            theta = np.ascontiguousarray(theta[:, nidx])
-            aw = aw[nidx]
-            sb.resample(nidx)  # :74
-            mlr = float(np.mean(gx[nidx])) * math.exp(lml)
-            k_log[0] += N
-            mtd_gx = gx[nidx].copy()
-            for _ in range(n_props):  # :85
-                centre = mu[:, None] if ind_prop else theta
-                theta_f = propd.draw(rng, 1.0 if ind_prop else tj, centre, N)  # :87
-                prtf = np.array([prior.logpdf(theta_f[:, p]) for p in range(N)])
-                ok = np.isfinite(prtf)
-                if not ok.any():
-                    continue
-                th_run = np.where(ok[None, :], theta_f, theta)  # invalid proposals run a harmless theta, then are ignored
-                if obs_i == 1:  # :92-94
-                    gx_f = sb.propose(th_run, 1, 1, next_seed())
-                    aw_f = gx_f.copy()
-                else:  # :95-100
-                    aw_f = sb.propose(th_run, 1, obs_i - 1, next_seed())
-                    gx_f = sb.propose(th_run, obs_i, obs_i, next_seed())
-                    aw_f = aw_f + gx_f
-                aw_f = aw_f + prtf
-                log_ratio = aw_f - aw
-                if proposal_correction and ind_prop:
-                    log_ratio = log_ratio + propd.logpdf_centred(theta - mu[:, None]) - propd.logpdf_centred(theta_f - mu[:, None])
-                u = rng.random(N)
-                with np.errstate(over="ignore", invalid="ignore"):
-                    accept = ok & (np.exp(log_ratio) > u)  # :104
-                accept &= ~np.isnan(aw_f)
-                if accept.any():
-                    mtd_gx[accept] = np.exp(gx_f[accept])
-                    theta[:, accept] = theta_f[:, accept]
-                    aw[accept] = aw_f[accept]
-                    sb.accept(accept)  # pop[p] .= pop_f  :109
-                n_acc = int(accept.sum())
-                k_log[1] += n_acc
-                tj *= alpha ** n_acc * 0.999 ** int(ok.sum() - n_acc)  # :111-113, applied per sweep
-            bme[1] += math.log(mlr / float(np.mean(mtd_gx)))  # :118
-            w[:] = 1.0
-        else:
-            bme[1] += math.log(np.sum(w * gx) / np.sum(w))  # :121 (with the updated w, as in the reference)
-        obs_min = obs_i + 1
-    mu, cv = compute_is_mu_covar(theta, w)
-    out = ImportanceSample(mu, cv, theta, w, time.perf_counter_ns() - start, -bme,
-                           acceptance_rate=(k_log[1] / k_log[0]) if k_log[0] else float("nan"), n_resample=n_resample)
-    if verbose:
-        ar = f"{100.0 * out.acceptance_rate:.3g}" if k_log[0] else "n/a"
-        print(f"- finished in {out.run_time / 1e9:.1f} seconds (AR = {ar}%)")
-    sb.close()
+        out = ImportanceSample(mu, cv, theta, w, time.perf_counter_ns() - start, -bme,
+                               acceptance_rate=(k_log[1] / k_log[0]) if k_log[0] else float("nan"), n_resample=n_resample,
+                               status=int(getattr(bank, "status_accum", 0)))
+        if verbose:
+            ar = f"{100.0 * out.acceptance_rate:.3g}" if k_log[0] else "n/a"
+            print(f"- finished in {out.run_time / 1e9:.1f} seconds (AR = {ar}%)")
+    finally:
+        sb.close()  # frees both device populations, also when a filter call raised
     return out
 
 
 def run_smc2_analysis(model: DPOMPModel, obs_data, np_: int = C_DF_SMC2_P, npf: int = C_DF_PF_P,
                       ess_rs_crit: float = C_DF_ESS_CRIT, ind_prop: bool = True, alpha: float = C_ACCEPTANCE_ALPHA,
-                      seed: int = 1, device: int = 0, verbose: bool = True, proposal_correction: bool = False,
+                      seed: int = 1, device: Optional[int] = None, verbose: bool = True, proposal_correction: bool = False,
                       distributed: bool = False) -> ImportanceSample:
     """``run_smc2_analysis(model, obs_data; np, npf, ess_rs_crit, ind_prop, alpha)`` (src/DiscretePOMP.jl:251-257).
     (``np_`` because ``np`` is numpy here.)"""
     rng = np.random.default_rng(seed)
+    if device is None:  # one process per GPU: a rank of a distributed run drives the GPU of its LOCAL_RANK
+        device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
     bank = ParticleFilter(model, obs_data, device=device)
     theta_init = model.prior.rand(rng, np_)  # rand(mdl.prior, np)
     if verbose:
@@ -220,7 +235,7 @@ def run_smc2_analysis(model: DPOMPModel, obs_data, np_: int = C_DF_SMC2_P, npf: 
 
 def run_ibis_analysis(model: DPOMPModel, obs_data, algorithm: str = C_ALG_NM_SMC2, np_: Optional[int] = None,
                       ind_prop: Optional[bool] = None, ess_rs_crit: Optional[float] = None,
-                      alpha: float = C_ACCEPTANCE_ALPHA, npf: int = C_DF_PF_P, seed: int = 1, device: int = 0,
+                      alpha: float = C_ACCEPTANCE_ALPHA, npf: int = C_DF_PF_P, seed: int = 1, device: Optional[int] = None,
                       verbose: bool = True, proposal_correction: bool = False, distributed: bool = False
                       ) -> ImportanceSample:
     """``run_ibis_analysis`` (src/DiscretePOMP.jl:289-302).  Only the default algorithm, SMC^2, sits on

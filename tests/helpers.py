@@ -38,3 +38,34 @@ class OracleBank:
         theta = np.asarray(theta)
         return np.array([self.orc.pf_partial(self.desc, pop.pops[b], theta[:, b], ymin, ymax, seed=seed, seg=seg_base + b).ll
                          for b in range(pop.B)])
+
+
+# every catalogue model of generate_model (src/hmm_examples.jl:171-204), density and frequency dependent:
+# (name, initial condition, freq_dep, a parameter vector that gives an outbreak)
+CATALOGUE_CASES = [
+    ("SI", [100, 1], False, [0.003]),
+    ("SI", [100, 1], True, [0.3]),
+    ("SIR", [100, 1, 0], False, [0.003, 0.1]),
+    ("SIR", [100, 1, 0], True, [0.3, 0.1]),
+    ("SIS", [100, 1], False, [0.003, 0.1]),
+    ("SIS", [100, 1], True, [0.3, 0.1]),
+    ("SEI", [100, 0, 1], False, [0.005, 0.2]),
+    ("SEI", [100, 0, 1], True, [0.5, 0.2]),
+    ("SEIR", [100, 0, 1, 0], False, [0.005, 0.2, 0.1]),
+    ("SEIR", [100, 0, 1, 0], True, [0.5, 0.2, 0.1]),
+    ("SEIS", [100, 0, 1], False, [0.005, 0.2, 0.1]),
+    ("SEIS", [100, 0, 1], True, [0.5, 0.2, 0.1]),
+    ("LOTKA", [70, 70], False, [0.5, 0.0025, 0.3]),
+    ("ROSSMAC", [100, 10, 200, 20], False, [0.02, 0.05, 0.04, 0.1]),
+]
+
+
+def synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99, obs_ids=None):
+    """Observations simulated with the oracle's forward simulator (the default flow of the reference:
+    gillespie_sim with dmy_obs_fn, y.val = state)."""
+    times = [tmax * (i + 1) / T for i in range(T)]
+    blank = [dp.Observation(t, 1, 1.0, [0] * model.n_states) for t in times]
+    d = dp.ModelDescriptor(model, blank)
+    traj = orc.simulate(d, 1, theta, seed=seed)  # [T][S][1]
+    ids = obs_ids or [1] * T
+    return [dp.Observation(t, ids[i], 1.0, [int(v) for v in traj[i, :, 0]]) for i, t in enumerate(times)]

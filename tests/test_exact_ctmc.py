@@ -1,0 +1,98 @@
+"""RNG-independent pins beyond Pooley SIS: exact CTMC likelihoods of the SEIR and Lotka-Volterra data sets
+(oracle/exact_ctmc.py, golden values in tests/golden/exact_ctmc.json made by tests/golden/make_exact_ctmc.py), the
+oracle's unbiasedness against them in both of its modes, and the SPEC <-> FAITHFUL bound on every catalogue model."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from helpers import CATALOGUE_CASES, synthetic_data
+from oracle import exact_ctmc, exact_sis
+
+EXACT = json.load(open(os.path.join(GOLDEN, "exact_ctmc.json")))
+SEIR_X0, LOTKA_X0 = [100, 0, 1, 0], [70, 70]
+
+
+@pytest.mark.parametrize("theta", [(0.003, 0.1), (0.0032, 0.1), (0.0025, 0.08), (0.004, 0.15)])
+def test_generic_ctmc_oracle_reproduces_the_dense_sis_one(theta):
+    """Sparse generator + uniformisation (any model) against the dense expm of oracle/exact_sis.py."""
+    want = exact_sis.exact_sis_loglik(theta, [100, 1], exact_sis.POOLEY_TIMES, exact_sis.POOLEY_CASES)[0]
+    got = exact_ctmc.exact_loglik("SIS", theta, [100, 1], exact_sis.POOLEY_TIMES, exact_sis.POOLEY_CASES)
+    assert got["n_states"] == 102 and abs(got["ll"] - want) < 1e-9 and got["truncation"] < 1e-12
+
+
+def test_seir_golden_value_is_reproducible(dp):
+    y = dp.get_observations(os.path.join(GOLDEN, "seir_synthetic.csv"))
+    g = EXACT["SEIR"][0]
+    r = exact_ctmc.exact_loglik("SEIR", g["theta"], SEIR_X0, [o.time for o in y], [o.val[2] for o in y])
+    assert r["n_states"] == g["n_states"] == 182002   # (S, E, I) with S <= 100, S + E + I <= 101, minus unreachable ones
+    assert abs(r["ll"] - g["ll"]) < 1e-9 and r["leak"] == 0.0
+    assert np.allclose(r["increments"], g["increments"], atol=1e-9)
+
+
+def test_lotka_box_truncation_has_converged():
+    a, b = EXACT["LOTKA"]
+    assert a["bound"] < b["bound"] and abs(a["ll"] - b["ll"]) < 1e-5 and b["leak"] < 1e-10
+    assert a["ll"] <= b["ll"] + 1e-9  # absorbed mass only ever lowers the value
+
+
+@pytest.mark.parametrize("mode", ["spec", "faithful"])
+@pytest.mark.parametrize("which", [0, 2])
+def test_oracle_is_unbiased_against_the_exact_seir_likelihood(dp, orc, mode, which):
+    """E[exp(ll_hat)] = p(y | theta) for SEIR (obs seq = 3, seir_rf): pins the oracle's SEIR rate function,
+    transition matrix and observed component without any random number."""
+    y = dp.get_observations(os.path.join(GOLDEN, "seir_synthetic.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("SEIR", SEIR_X0), y)
+    g = EXACT["SEIR"][which]
+    m = orc.MODE_SPEC if mode == "spec" else orc.MODE_FAITHFUL
+    R = 128
+    lls = np.array([orc.pf_loglik(desc, 1024, g["theta"], seed=s, mode=m).ll for s in range(1, R + 1)])
+    ratio = np.exp(lls - g["ll"])
+    se = ratio.std(ddof=1) / math.sqrt(R)
+    assert abs(ratio.mean() - 1.0) < 3.5 * se and se < 0.02, (ratio.mean(), se)
+    assert abs((g["ll"] - lls.mean()) - lls.var() / 2) < 0.03
+
+
+def test_oracle_is_unbiased_against_the_exact_lotka_likelihood(dp, orc):
+    y = dp.get_observations(os.path.join(GOLDEN, "lotka_synthetic.csv"))
+    desc = dp.ModelDescriptor(dp.generate_model("LOTKA", LOTKA_X0), y)
+    g = EXACT["LOTKA"][1]
+    R = 48
+    lls = np.array([orc.pf_loglik(desc, 2048, g["theta"], seed=s, nthreads=4).ll for s in range(1, R + 1)])
+    ratio = np.exp(lls - g["ll"])
+    se = ratio.std(ddof=1) / math.sqrt(R)
+    assert abs(ratio.mean() - 1.0) < 3.5 * se, (ratio.mean(), se)
+
+
+@pytest.mark.parametrize("name,x0,fd,theta", CATALOGUE_CASES)
+def test_spec_mode_tracks_faithful_mode_on_every_catalogue_model(dp, orc, name, x0, fd, theta):
+    """SPEC (what the GPU computes) against FAITHFUL (the reference's Float64 left fold, libm log/exp, rsp_systematic
+    verbatim) on all catalogue rate functions: same event counts, log-likelihood within 1e-11, ancestors equal except
+    where a resampling point falls within rounding of a boundary."""
+    model = dp.generate_model(name, x0, freq_dep=fd)
+    desc = dp.ModelDescriptor(model, synthetic_data(dp, orc, model, theta))
+    diff = 0
+    for seed in (1, 2, 3):
+        a = orc.pf_loglik(desc, 1024, theta, seed=seed, mode=orc.MODE_SPEC, trace=True)
+        b = orc.pf_loglik(desc, 1024, theta, seed=seed, mode=orc.MODE_FAITHFUL, trace=True)
+        assert a.events == b.events
+        assert (math.isinf(a.ll) and a.ll == b.ll) or abs(a.ll - b.ll) < 1e-11, (a.ll, b.ll)
+        diff += int((a.ancestors != b.ancestors).sum())
+    assert diff <= 2
+
+
+def test_spec_mode_tracks_faithful_mode_with_t0_index_and_unweighted_rows(dp, orc, make_obs):
+    """Unknown initial time (t0_index) and an obs_id = 0 row (propagate only: no weight, no resampling)."""
+    rf = dp.RateFunction([dp.RateTerm(1, ((1,), (2,))), dp.RateTerm(2, ((2,),))])
+    model = dp.generate_custom_model("SIS", rf, [100, 1], [[-1, 1], [1, -1]], t0_index=3)
+    y = make_obs([20.0, 30.0, 40.0, 60.0], [[0, 18], [0, 0], [0, 65], [0, 70]], obs_ids=[1, 0, 1, 1])
+    desc = dp.ModelDescriptor(model, y)
+    for seed in (1, 2, 3, 4):
+        a = orc.pf_loglik(desc, 1024, [0.003, 0.1, 4.5], seed=seed, mode=orc.MODE_SPEC, trace=True)
+        b = orc.pf_loglik(desc, 1024, [0.003, 0.1, 4.5], seed=seed, mode=orc.MODE_FAITHFUL, trace=True)
+        assert a.events == b.events and abs(a.ll - b.ll) < 1e-11
+        assert a.per_obs_ll[1] == 0.0 and b.per_obs_ll[1] == 0.0
+        assert int((a.ancestors != b.ancestors).sum()) <= 1
