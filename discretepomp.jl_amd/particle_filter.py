@@ -176,7 +176,7 @@ class ParticleFilter:
         """Keeps the per-segment status words of the call and reacts to DPOMP_ST_EVENT_CAP: a capped particle's
         weight is zero, so the estimate of its filter is not the reference's (states are int32 on the device,
         values stay below 2^30 by the cap on events and the checks at create/upload)."""
-        self._note_status(status)
+        self.last_status = status
         self.status_accum |= int(np.bitwise_or.reduce(status)) if status.size else 0
         if self.on_event_cap != "ignore" and np.any(status & _abi.ST_EVENT_CAP):
             n = int(np.count_nonzero(status & _abi.ST_EVENT_CAP))
