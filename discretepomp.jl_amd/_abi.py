@@ -29,6 +29,7 @@ RS_SYSTEMATIC, RS_STRATIFIED, RS_MULTINOMIAL = 1, 2, 3
  BUILTIN_SEI_FD, BUILTIN_SEIR_FD, BUILTIN_LOTKA, BUILTIN_ROSSMAC) = range(11)
 BUILTIN_USER = 100
 DBG_LOGW, DBG_OFFSPRING_END = 1, 2
+EVALUATOR_BUILTIN, EVALUATOR_TABLE, EVALUATOR_TABLE_COMPILED, EVALUATOR_SOURCE = 1, 2, 3, 4
 STATIC_MAX_BYTES = 16 << 20
 STATIC_MAX_SEGMENTS = 4096
 
@@ -92,6 +93,8 @@ _PROTOTYPES = {
     "dpomp_pf_loglik_static": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_uint64,
                                          C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "dpomp_abi_sizeof": (C.c_int, [C.c_int]),
+    "dpomp_get_evaluator": (C.c_int, [C.c_void_p]),
+    "dpomp_set_generic_jit": (C.c_int, [C.c_int]),
     "dpomp_pop_alloc": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
     "dpomp_pop_free": (None, [C.c_void_p, C.c_void_p]),
     "dpomp_pf_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_int32,

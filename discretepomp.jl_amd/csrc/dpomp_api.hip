@@ -10,11 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <hip/hiprtc.h>
 
 #include "../../include/dpomp.h"
@@ -132,6 +135,9 @@ struct dpomp_handle {
     bool rtc = false;
     hipModule_t rtc_module = nullptr;
     hipFunction_t rtc_prop1 = nullptr, rtc_propc = nullptr, rtc_sim = nullptr, rtc_small = nullptr;
+    hipFunction_t rtc_q2 = nullptr, rtc_q4 = nullptr, rtc_c16 = nullptr;
+    int evaluator = 0;  // DPOMP_EVALUATOR_*
+    std::string jit_note;  // why a table model was not compiled (it then runs in the interpreter)
     // observation data on the device (k_filter_small loops over the observations inside the kernel)
     double* d_obs_time = nullptr;
     long long* d_ysum = nullptr;
@@ -635,7 +641,6 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             if (rpl == 0)
                 rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil)
                           ? kDefaultPropVariant : 1;  // lane_util = -1 (not measured yet) -> compaction
-            if (h->rtc && rpl != 32) rpl = 1;  // run-time compiled models come in two variants
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             // iterate_particles! :56
             HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
@@ -789,18 +794,105 @@ RtcApi* rtc_api() {  // loaded on first use only: the library itself does not de
     return &api;
 }
 
-constexpr int kRtcKernels = 4;
-const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>", "dpomp::k_propagate_c<dpomp::RUser, 32>",
-                                            "dpomp::k_simulate_rec<dpomp::RUser>", "dpomp::k_filter_small<dpomp::RUser>"};
+constexpr int kRtcKernels = 7;
+const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>",       "dpomp::k_propagate_c<dpomp::RUser, 32>",
+                                            "dpomp::k_simulate_rec<dpomp::RUser>",    "dpomp::k_filter_small<dpomp::RUser>",
+                                            "dpomp::k_propagate_q<dpomp::RUser, 2>",  "dpomp::k_propagate_q<dpomp::RUser, 4>",
+                                            "dpomp::k_propagate_c<dpomp::RUser, 16>"};
+const char* const kRtcOptions[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
+                                   "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
+constexpr int kRtcOptionCount = (int)(sizeof kRtcOptions / sizeof kRtcOptions[0]);
 
-// Compiles kernels + user source.  On success `code` holds the gfx950 code object and `lowered` the mangled names.
-int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<char>& code, std::string lowered[kRtcKernels],
-                std::string& log) {
-    RtcApi* api = rtc_api();
-    if (!api) {
-        log = "hipRTC (libhiprtc.so) could not be loaded";
-        return DPOMP_EDEVICE;
+// ---- cache of compiled models -------------------------------------------------------------------------------
+// Compiling the kernels with a rate function takes seconds; the result depends only on the text that goes into the
+// compiler.  Code objects are therefore kept under a 128-bit hash of (kernel headers, wrapper, rate source, options,
+// HIP runtime version): in this process, and as files in $DPOMP_CACHE_DIR (default ~/.cache/dpomp; "off" disables
+// the files).  A cache file = magic, the lowered kernel names, the code object; written to a temporary name and
+// renamed, so a reader never sees half a file; anything unreadable or of the wrong shape is ignored and recompiled.
+struct RtcBinary {
+    std::vector<char> code;
+    std::string lowered[kRtcKernels];
+};
+std::mutex g_rtc_cache_mutex;
+std::map<std::string, RtcBinary> g_rtc_cache;
+int g_generic_jit = -1;  // dpomp_set_generic_jit: -1 = environment / default (on), 0 = off, 1 = on
+
+std::string hash_hex(const std::string& text) {
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+    for (unsigned char c : text) {
+        a = (a ^ c) * 0x100000001b3ull;
+        b = (b ^ (c + 0x9e)) * 0x100000001b3ull;
+        b ^= b >> 29;
     }
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
+    return buf;
+}
+
+std::string cache_dir() {
+    const char* d = getenv("DPOMP_CACHE_DIR");
+    if (d && !strcmp(d, "off")) return "";
+    if (d && *d) return d;
+    const char* home = getenv("HOME");
+    if (!home || !*home) return "";
+    return std::string(home) + "/.cache/dpomp";
+}
+
+void make_dirs(const std::string& path) {
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+}
+
+bool cache_file_read(const std::string& file, RtcBinary& out) {
+    FILE* f = fopen(file.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8];
+    uint32_t n = 0;
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT2", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
+        ok = true;
+        for (int i = 0; ok && i < kRtcKernels; ++i) {
+            uint32_t len = 0;
+            ok = fread(&len, 4, 1, f) == 1 && len > 0 && len < 4096;
+            if (ok) {
+                out.lowered[i].resize(len);
+                ok = fread(&out.lowered[i][0], 1, len, f) == len;
+            }
+        }
+        uint64_t cs = 0;
+        ok = ok && fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 30);
+        if (ok) {
+            out.code.resize((size_t)cs);
+            ok = fread(out.code.data(), 1, (size_t)cs, f) == (size_t)cs && fgetc(f) == EOF;
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+void cache_file_write(const std::string& dir, const std::string& file, const RtcBinary& b) {
+    make_dirs(dir);
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp.%d.%p", (int)getpid(), (const void*)&b);
+    const std::string tmpname = file + tmp;
+    FILE* f = fopen(tmpname.c_str(), "wb");
+    if (!f) return;
+    const uint32_t n = kRtcKernels;
+    bool ok = fwrite("DPOMPRT2", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
+    for (int i = 0; ok && i < kRtcKernels; ++i) {
+        const uint32_t len = (uint32_t)b.lowered[i].size();
+        ok = fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[i].data(), 1, len, f) == len;
+    }
+    const uint64_t cs = b.code.size();
+    ok = ok && fwrite(&cs, 8, 1, f) == 1 && fwrite(b.code.data(), 1, b.code.size(), f) == b.code.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmpname.c_str(), file.c_str()) != 0) (void)remove(tmpname.c_str());
+}
+
+// Compiles kernels + rate source (or finds the result in the cache).  On success `bin` holds the gfx950 code object
+// and the mangled kernel names; `from_cache` tells which.
+int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& bin, std::string& log, bool* from_cache = nullptr) {
+    if (from_cache) *from_cache = false;
     char head[512];
     snprintf(head, sizeof head, "#include \"dpomp_kernels.h\"\nnamespace dpomp {\n#line 1 \"rate_source\"\n");
     const bool user_obs = d->obs.kind == DPOMP_OBS_USER;
@@ -814,6 +906,37 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
                         "{ return dpomp_user_obs(th, x, y, ny); }\n"
                       : "");
     const std::string src = std::string(head) + rate_source + tail;
+
+    std::string keytext = src;
+    for (const char* o : kRtcOptions) keytext += std::string("\x01") + o;
+    for (const char* n : kRtcNames) keytext += std::string("\x02") + n;
+    int rt_version = 0;
+    (void)hipRuntimeGetVersion(&rt_version);
+    keytext += "\x03" + std::to_string(rt_version) + "\x03" + kSrcKernels + "\x03" + kSrcNumerics + "\x03" + kSrcLogTable;
+    const std::string key = hash_hex(keytext);
+    const std::string dir = cache_dir();
+    const std::string file = dir.empty() ? "" : dir + "/" + key + ".gfx950.dpomprtc";
+    {
+        std::lock_guard<std::mutex> lock(g_rtc_cache_mutex);
+        auto it = g_rtc_cache.find(key);
+        if (it != g_rtc_cache.end()) {
+            bin = it->second;
+            if (from_cache) *from_cache = true;
+            return DPOMP_OK;
+        }
+    }
+    if (!file.empty() && cache_file_read(file, bin)) {
+        std::lock_guard<std::mutex> lock(g_rtc_cache_mutex);
+        g_rtc_cache[key] = bin;
+        if (from_cache) *from_cache = true;
+        return DPOMP_OK;
+    }
+
+    RtcApi* api = rtc_api();
+    if (!api) {
+        log = "hipRTC (libhiprtc.so) could not be loaded";
+        return DPOMP_EDEVICE;
+    }
     const char* headers[3] = {kSrcKernels, kSrcNumerics, kSrcLogTable};
     const char* names[3] = {"dpomp_kernels.h", "dpomp_numerics.h", "dpomp_log_table.h"};
     hiprtcProgram prog;
@@ -822,9 +945,7 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
         return DPOMP_EDEVICE;
     }
     for (const char* n : kRtcNames) api->add_name(prog, n);
-    const char* opts[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
-                          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
-    const hiprtcResult r = api->compile(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    const hiprtcResult r = api->compile(prog, kRtcOptionCount, kRtcOptions);
     size_t ls = 0;
     if (api->log_size && api->log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
         log.resize(ls);
@@ -838,25 +959,82 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, std::vector<
         for (int i = 0; i < kRtcKernels; ++i) {
             const char* ln = nullptr;
             if (api->lowered(prog, kRtcNames[i], &ln) != HIPRTC_SUCCESS || !ln) rc = DPOMP_EDEVICE;
-            else lowered[i] = ln;
+            else bin.lowered[i] = ln;
         }
         size_t cs = 0;
         if (rc == DPOMP_OK && api->code_size(prog, &cs) == HIPRTC_SUCCESS && cs) {
-            code.resize(cs);
-            if (api->get_code(prog, code.data()) != HIPRTC_SUCCESS) rc = DPOMP_EDEVICE;
+            bin.code.resize(cs);
+            if (api->get_code(prog, bin.code.data()) != HIPRTC_SUCCESS) rc = DPOMP_EDEVICE;
         } else if (rc == DPOMP_OK) {
             rc = DPOMP_EDEVICE;
         }
     }
     api->destroy(&prog);
+    if (rc == DPOMP_OK) {
+        if (!file.empty()) cache_file_write(dir, file, bin);
+        std::lock_guard<std::mutex> lock(g_rtc_cache_mutex);
+        g_rtc_cache[key] = bin;
+    }
     return rc;
+}
+
+// Loads a compiled model into the handle (module + the seven kernels).
+int rtc_load(dpomp_handle* h, const RtcBinary& bin, std::string& why) {
+    hipError_t me = hipModuleLoadData(&h->rtc_module, bin.code.data());
+    hipFunction_t* fns[kRtcKernels] = {&h->rtc_prop1, &h->rtc_propc, &h->rtc_sim, &h->rtc_small, &h->rtc_q2, &h->rtc_q4, &h->rtc_c16};
+    for (int i = 0; me == hipSuccess && i < kRtcKernels; ++i) me = hipModuleGetFunction(fns[i], h->rtc_module, bin.lowered[i].c_str());
+    if (me != hipSuccess) {
+        why = hipGetErrorString(me);
+        if (h->rtc_module) (void)hipModuleUnload(h->rtc_module);
+        h->rtc_module = nullptr;
+        return DPOMP_EDEVICE;
+    }
+    h->rtc = true;
+    return DPOMP_OK;
+}
+
+// The rate table of a descriptor as device source: the arithmetic of RGeneric::rates (dpomp_kernels.h), operation for
+// operation, with everything the interpreter decides at run time (which parameter, which components, which form)
+// decided by the text -- so a table model runs at the speed of a compiled-in evaluator with the same bits.
+std::string rate_table_source(const dpomp_model_desc* d) {
+    auto msum = [&](uint32_t mask) {
+        std::string e;
+        for (int i = 0; i < d->n_states; ++i)
+            if (mask & (1u << i)) e += (e.empty() ? "x[" : " + x[") + std::to_string(i) + "]";
+        return "(" + e + ")";
+    };
+    std::string s = "__device__ __forceinline__ void dpomp_user_rates(const double* theta, const int* x, double* r) {\n";
+    for (int e = 0; e < d->n_events; ++e) {
+        const dpomp_rate_term& t = d->rate[e];
+        const std::string th = "theta[" + std::to_string(t.theta_index) + "]", re = "r[" + std::to_string(e) + "]";
+        if (t.form == DPOMP_RATE_LEFT) {
+            s += "    { double v = " + th + ";";
+            for (int f = 0; f < t.n_factors; ++f) s += " v = v * (double)" + msum(t.factor_mask[f]) + ";";
+            if (t.denom_mask) s += " v = v / (double)" + msum(t.denom_mask) + ";";
+            s += " " + re + " = v; }\n";
+        } else {
+            s += "    { long long p = 1;";
+            for (int f = 0; f < t.n_factors; ++f) s += " p *= (long long)" + msum(t.factor_mask[f]) + ";";
+            s += " double q = (double)p;";
+            if (t.denom_mask) s += " q = q / (double)" + msum(t.denom_mask) + ";";
+            s += " " + re + " = " + th + " * q; }\n";
+        }
+    }
+    return s + "}\n";
+}
+
+bool generic_jit_enabled() {
+    if (g_generic_jit >= 0) return g_generic_jit != 0;
+    const char* env = getenv("DPOMP_GENERIC_JIT");
+    return !(env && !strcmp(env, "0"));
 }
 
 // One launch site for the propagation kernel: compiled-in template instance or run-time compiled module function.
 hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a) {
     if (h->rtc) {
         void* params[] = {&a};
-        return timed_module_launch(h, KID_PROPAGATE, variant == 32 ? h->rtc_propc : h->rtc_prop1, grid, block, st, params);
+        hipFunction_t f = variant == 4 ? h->rtc_q4 : variant == 2 ? h->rtc_q2 : variant == 16 ? h->rtc_c16 : variant == 32 ? h->rtc_propc : h->rtc_prop1;
+        return timed_module_launch(h, KID_PROPAGATE, f, grid, block, st, params);
     }
     PropFn fn = variant == 4 ? h->prop.q4 : variant == 2 ? h->prop.q2 : variant == 16 ? h->prop.c16 : variant == 32 ? h->prop.c32 : h->prop.fn1;
     timed_launch(h, KID_PROPAGATE, fn, grid, block, 0, st, a);
@@ -897,9 +1075,9 @@ int dpomp_check_rate_source(const dpomp_model_desc* d, const char* rate_source, 
     int rc = validate_desc(d);
     if (rc != DPOMP_OK) return rc;
     if (!rate_source) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
-    std::vector<char> code;
-    std::string lowered[kRtcKernels], text;
-    rc = rtc_compile(d, rate_source, code, lowered, text);
+    RtcBinary bin;
+    std::string text;
+    rc = rtc_compile(d, rate_source, bin, text);
     if (log && log_size > 0) {
         strncpy(log, text.c_str(), (size_t)log_size - 1);
         log[log_size - 1] = 0;
@@ -989,31 +1167,33 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     }
     for (const PropEntry& pe : kPropTable)
         if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
+    h->evaluator = h->prop.fn1 ? DPOMP_EVALUATOR_BUILTIN : DPOMP_EVALUATOR_TABLE;
     if (rate_source) {
-        std::vector<char> code;
-        std::string lowered[kRtcKernels], text;
-        rc = rtc_compile(d, rate_source, code, lowered, text);
+        RtcBinary bin;
+        std::string text;
+        rc = rtc_compile(d, rate_source, bin, text);
         if (rc != DPOMP_OK) {
             rc = fail(nullptr, rc, "rate source does not compile: %.400s", text.c_str());
-            (void)hipStreamDestroy(h->own_stream);
-            delete h;
+            dpomp_destroy(h);
             return rc;
         }
-        hipError_t me = hipModuleLoadData(&h->rtc_module, code.data());
-        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_prop1, h->rtc_module, lowered[0].c_str());
-        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_propc, h->rtc_module, lowered[1].c_str());
-        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_sim, h->rtc_module, lowered[2].c_str());
-        if (me == hipSuccess) me = hipModuleGetFunction(&h->rtc_small, h->rtc_module, lowered[3].c_str());
-        if (me != hipSuccess) {
-            rc = fail(nullptr, DPOMP_EDEVICE, "loading the compiled rate module: %s", hipGetErrorString(me));
-            (void)hipStreamDestroy(h->own_stream);
-            delete h;
+        if (rtc_load(h, bin, text) != DPOMP_OK) {
+            rc = fail(nullptr, DPOMP_EDEVICE, "loading the compiled rate module: %s", text.c_str());
+            dpomp_destroy(h);
             return rc;
         }
-        h->rtc = true;
+        h->evaluator = DPOMP_EVALUATOR_SOURCE;
     } else if (!h->prop.fn1) {
-        h->prop = generic_set(d->n_states, d->n_events);
+        h->prop = generic_set(d->n_states, d->n_events);  // the table interpreter: always there as the fallback
         h->prop_is_generic = true;
+        if (generic_jit_enabled()) {  // a table model outside the catalogue: compile its table (cached), else interpret it
+            RtcBinary bin;
+            std::string text;
+            if (rtc_compile(d, rate_table_source(d).c_str(), bin, text) == DPOMP_OK && rtc_load(h, bin, text) == DPOMP_OK)
+                h->evaluator = DPOMP_EVALUATOR_TABLE_COMPILED;
+            else
+                h->jit_note = text;
+        }
     }
     if (const char* env = getenv("DPOMP_RPL")) h->force_rpl = atoi(env);
     {
@@ -1146,6 +1326,14 @@ int dpomp_pf_loglik_static(dpomp_handle* h, const double* theta, int64_t B, int6
     view.h_theta = h->static_h_theta;
     return run_partial(h, &view, theta, 1, h->T, seed, seg_base, DOMAIN_PROPAGATE, out_ll, out_status, nullptr);
 }
+
+int dpomp_set_generic_jit(int mode) {
+    if (mode < -1 || mode > 1) return DPOMP_EINVAL;
+    g_generic_jit = mode;
+    return DPOMP_OK;
+}
+
+int dpomp_get_evaluator(const dpomp_handle* h) { return h ? h->evaluator : DPOMP_EINVAL; }
 
 int dpomp_abi_sizeof(int which) {
     switch (which) {

@@ -126,7 +126,7 @@ class ParticleFilter:
 
     def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], device: int = 0, rs_type: int = 1,
                  essc: float = C_DF_ESS_CRIT, force_generic: bool = False, ess_adaptive: bool = False,
-                 on_event_cap: str = "warn"):
+                 on_event_cap: str = "warn", jit: Optional[bool] = None):
         self._lib = _abi.load_library()
         self._h = C.c_void_p()
         self.device = int(device)
@@ -134,14 +134,30 @@ class ParticleFilter:
         self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic)
         self.n_states, self.n_params, self.n_obs = self.desc.n_states, self.desc.n_params, self.desc.n_obs
         self.essc = essc  # accepted and unused, as in the reference (src/hmm_particle_filter.jl:63-68)
+        # a rate table outside the catalogue is compiled at create time (cached; jit=False: interpret it on the device;
+        # None: the library default, on unless DPOMP_GENERIC_JIT=0)
+        if jit is not None:
+            self._lib.dpomp_set_generic_jit(1 if jit else 0)
+        try:
+            rc = self._create()
+        finally:
+            if jit is not None:
+                self._lib.dpomp_set_generic_jit(-1)
+        if rc != _abi.OK:
+            self._h = C.c_void_p()
+            raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
+        self._finish_init(rs_type, essc, ess_adaptive, on_event_cap)
+
+    def _create(self) -> int:
+        device = self.device
         if self.desc.rate_source is not None:  # arbitrary rate code: compiled with hipRTC into the kernels
             rc = self._lib.dpomp_create_with_source(self.desc.byref(), int(device), self.desc.rate_source.encode(),
                                                     C.byref(self._h))
         else:
             rc = self._lib.dpomp_create(self.desc.byref(), int(device), C.byref(self._h))
-        if rc != _abi.OK:
-            self._h = C.c_void_p()
-            raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
+        return rc
+
+    def _finish_init(self, rs_type, essc, ess_adaptive, on_event_cap):
         self.rs_type = rs_type
         self._check(self._lib.dpomp_set_resampler(self._h, int(rs_type)))
         self._pops = weakref.WeakSet()  # live populations: freed with the handle if the caller did not
@@ -185,6 +201,12 @@ class ParticleFilter:
             if self.on_event_cap == "raise":
                 raise DpompError(_abi.ESTATE, msg)
             warnings.warn(msg, EventCapWarning, stacklevel=3)
+
+    @property
+    def evaluator(self) -> int:
+        """How rates are evaluated: 1 compiled-in (catalogue), 2 table interpreted on the device, 3 table compiled at
+        create time, 4 user rate source."""
+        return int(self._lib.dpomp_get_evaluator(self._h))
 
     def set_stream(self, raw_stream: Optional[int]):
         """Launch on an existing HIP stream, e.g. ``torch.cuda.current_stream().cuda_stream``."""

@@ -165,6 +165,20 @@ int dpomp_create(const dpomp_model_desc* desc, int device, dpomp_handle** out);
 int dpomp_create_with_source(const dpomp_model_desc* desc, int device, const char* rate_source, dpomp_handle** out);
 /* Compile-only check of a rate source (needs no GPU); the compiler log is copied into log[log_size]. */
 int dpomp_check_rate_source(const dpomp_model_desc* desc, const char* rate_source, char* log, int64_t log_size);
+/* How the handle evaluates rates: a model of the catalogue runs a compiled-in evaluator; a rate table outside the
+ * catalogue is turned into source at dpomp_create and compiled with hipRTC like a user's rate source (same arithmetic
+ * and bits as the table interpreter, the speed of a compiled-in evaluator); if hipRTC is unavailable, or the switch
+ * below is off, the table is interpreted on the device.  Compiled models are cached: in the process and as files under
+ * $DPOMP_CACHE_DIR (default ~/.cache/dpomp, "off" = no files), keyed by a hash of everything that goes into the
+ * compiler, so only the first create of a model pays the compile (seconds). */
+#define DPOMP_EVALUATOR_BUILTIN 1        /* compiled-in (catalogue)                        */
+#define DPOMP_EVALUATOR_TABLE 2          /* rate table interpreted on the device           */
+#define DPOMP_EVALUATOR_TABLE_COMPILED 3 /* rate table compiled at create time             */
+#define DPOMP_EVALUATOR_SOURCE 4         /* user rate source (dpomp_create_with_source)    */
+int dpomp_get_evaluator(const dpomp_handle* h);
+/* Process-wide switch for compiling rate tables: 1 on, 0 off (interpret), -1 default = on unless the environment has
+ * DPOMP_GENERIC_JIT=0.  Applies to handles created afterwards. */
+int dpomp_set_generic_jit(int mode);
 void dpomp_destroy(dpomp_handle* h);
 const char* dpomp_last_error(const dpomp_handle* h);
 /* Run the kernels on an existing HIP stream (hipStream_t passed as void*); NULL = the

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Rate tables outside the catalogue are compiled at create time by default (seconds per distinct model on first use).
+# The suite creates hundreds of table models, so it runs them in the device interpreter unless a test asks for the
+# compiled path (ParticleFilter(..., jit=True): tests/test_table_jit.py); compiled models of a run are cached in a
+# directory of its own.
+os.environ.setdefault("DPOMP_GENERIC_JIT", "0")
+os.environ.setdefault("DPOMP_CACHE_DIR", os.path.join(__import__("tempfile").gettempdir(), f"dpomp_cache_{os.getuid()}"))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
