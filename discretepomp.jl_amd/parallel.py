@@ -104,24 +104,75 @@ class LocalBank:
                 c()
 
 
+def migration_plan(nidx, N: int, world: int, rank: int):
+    """Who sends which populations to whom when the theta-particles are resampled with global ancestors ``nidx``
+    (src/hmm_ibis.jl:70-75) and block ``shard_bounds(N, world, r)`` lives on rank r.  A rank sends each of its
+    populations at most ONCE to each rank that needs it (duplicates are expanded by the receiver), so a rank receives
+    at most one population per slot of its block -- never the whole bank.  Everything is derived from ``nidx`` alone,
+    which every rank holds, so no plan has to be exchanged.
+
+    Returns a dict for ``rank``: ``send_rows`` (local row indices, grouped by destination rank in rank order),
+    ``send_counts`` / ``recv_counts`` ([world]), ``local_anc`` (for every slot of the block: the local row it copies
+    if its ancestor lives here, else the slot itself), ``remote_slots`` and ``remote_pick`` (slot b takes row
+    ``remote_pick`` of the receive buffer)."""
+    nidx = np.asarray(nidx, dtype=np.int64)
+    bounds = [shard_bounds(N, world, r) for r in range(world)]
+    owner = np.empty(N, dtype=np.int64)
+    for r, (lo, hi) in enumerate(bounds):
+        owner[lo:hi] = r
+    lo, hi = bounds[rank]
+    send_rows, send_counts = [], np.zeros(world, dtype=np.int64)
+    for dst, (dlo, dhi) in enumerate(bounds):  # what this rank sends: its rows that block `dst` descends from
+        if dst == rank:
+            continue
+        anc = nidx[dlo:dhi]
+        mine = np.unique(anc[owner[anc] == rank])
+        send_rows.append(mine - lo)
+        send_counts[dst] = len(mine)
+    anc = nidx[lo:hi]
+    src = owner[anc] if hi > lo else np.empty(0, dtype=np.int64)
+    recv_counts = np.zeros(world, dtype=np.int64)
+    local_anc = np.arange(hi - lo, dtype=np.int64)
+    here = src == rank
+    local_anc[here] = anc[here] - lo
+    remote_slots = np.flatnonzero(~here)
+    remote_pick = np.empty(len(remote_slots), dtype=np.int64)
+    offset = 0
+    for r in range(world):
+        if r == rank:
+            continue
+        sel = src[remote_slots] == r
+        uniq = np.unique(anc[remote_slots][sel])  # the order rank r sends them in
+        recv_counts[r] = len(uniq)
+        remote_pick[sel] = offset + np.searchsorted(uniq, anc[remote_slots][sel])
+        offset += len(uniq)
+    return {"send_rows": np.concatenate(send_rows) if send_rows else np.empty(0, dtype=np.int64),
+            "send_counts": send_counts, "recv_counts": recv_counts, "local_anc": local_anc,
+            "remote_slots": remote_slots, "remote_pick": remote_pick}
+
+
 class ShardedBank(LocalBank):
     """The same interface with the N theta-particles sharded over the process group: rank r owns the block
     ``shard_bounds(N, world, r)`` and its device-resident populations.  Filters run locally with the GLOBAL
     segment index in the RNG key; only log-likelihood vectors are all-gathered (8 B per theta-particle), except at
-    theta-level resampling (src/hmm_ibis.jl:70-75), where ancestors may live on another GPU: every rank
-    all-gathers the populations (int32 state, directly from device memory over RCCL) and keeps the rows of its
-    new block.  Results are bit-identical to :class:`LocalBank`."""
+    theta-level resampling (src/hmm_ibis.jl:70-75), where ancestors may live on another GPU: populations whose
+    ancestor is local are copied on the device, the others travel in ONE all-to-all in which every rank sends each
+    needed population once per destination, device to device when the group is ``nccl`` (RCCL; xGMI is a full mesh of
+    point-to-point links, so an all-to-all of direct sends is its natural collective).  A rank therefore receives at
+    most its own block's worth of populations (``last_migration``), not the whole bank.  Results are bit-identical to
+    :class:`LocalBank`."""
 
     def __init__(self, bank, N: int, npf: int, group=None):
         import torch.distributed as dist
         self.bank, self.N, self.group = bank, N, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.lo, self.hi = shard_bounds(N, self.world, self.rank)
-        self.width = -(-N // self.world)
         nb = max(self.hi - self.lo, 1)
         self.empty = self.hi == self.lo
         self.pop = bank.alloc_population(nb, npf)
         self.pop_f = bank.alloc_population(nb, npf)
+        self.last_migration = {"rows_sent": 0, "rows_received": 0, "rows_local": 0}
+        self.total_rows_received = 0
 
     def _local(self, pop, theta, ymin, ymax, seed):
         if self.empty:
@@ -138,21 +189,23 @@ class ShardedBank(LocalBank):
     def resample(self, nidx):
         import torch
         import torch.distributed as dist
-        mine = self.pop.export_state()
-        if dist.get_backend(self.group) != "nccl" and mine.is_cuda:
-            mine = mine.cpu()  # gloo group (tests, CPU-side rendezvous): stage the migration through the host
-        pad = torch.zeros((self.width,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
-        if not self.empty:
-            pad[: self.hi - self.lo] = mine
-        everything = torch.empty((self.world * self.width,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(everything, pad, group=self.group)
+        plan = migration_plan(nidx, self.N, self.world, self.rank)
+        on_device = dist.get_backend(self.group) == "nccl"
+        send = self.pop.export_rows(plan["send_rows"])  # a copy of the rows that leave, taken before anything moves
+        if not on_device and send.is_cuda:
+            send = send.cpu()  # gloo group (tests, CPU-side rendezvous): stage the migration through the host
+        n_recv = int(plan["recv_counts"].sum())
+        recv = torch.empty((n_recv,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send.contiguous(), [int(c) for c in plan["recv_counts"]],
+                               [int(c) for c in plan["send_counts"]], group=self.group)
+        self.last_migration = {"rows_sent": int(plan["send_counts"].sum()), "rows_received": n_recv,
+                               "rows_local": int(len(plan["local_anc"]) - len(plan["remote_slots"]))}
+        self.total_rows_received += n_recv
         if self.empty:
             return
-        rows = []
-        for g in np.asarray(nidx[self.lo:self.hi]):
-            r = shard_of(int(g), self.N, self.world)
-            rows.append(r * self.width + int(g) - shard_bounds(self.N, self.world, r)[0])
-        self.pop.import_state(everything[torch.as_tensor(rows, device=mine.device)])
+        self.pop.gather(plan["local_anc"])  # pop[b] <- pop[local ancestor] on the device
+        if len(plan["remote_slots"]):
+            self.pop.import_rows(plan["remote_slots"], recv[torch.as_tensor(plan["remote_pick"], device=recv.device)])
 
     def accept(self, mask):
         if self.empty:

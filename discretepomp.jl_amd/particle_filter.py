@@ -107,6 +107,21 @@ class Population:
         import torch
         torch.cuda.current_stream(self._pf.device).synchronize()
 
+    def export_rows(self, rows):
+        """Copy of the populations ``rows`` (segment indices) as an int32 tensor [len(rows), S, stride] on the device:
+        what this rank sends when theta-particles migrate."""
+        import torch
+        idx = torch.as_tensor(np.asarray(rows, dtype=np.int64), device=torch.device("cuda", self._pf.device))
+        return self.state_tensor(False).index_select(0, idx)
+
+    def import_rows(self, slots, rows):
+        """``pop[slots[i]] <- rows[i]`` (device or host tensor of the shape :meth:`export_rows` returns)."""
+        import torch
+        dev = torch.device("cuda", self._pf.device)
+        idx = torch.as_tensor(np.asarray(slots, dtype=np.int64), device=dev)
+        self.state_tensor(True).index_copy_(0, idx, rows.to(dev))
+        torch.cuda.current_stream(self._pf.device).synchronize()
+
     def take(self, other: "Population", take: Sequence[int]):
         """``self[b] <- other[take[b]]`` where ``take[b] >= 0`` (accepted PMMH proposals,
         src/hmm_ibis.jl:109)."""

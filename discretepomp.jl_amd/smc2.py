@@ -48,6 +48,7 @@ class ImportanceSample:
     acceptance_rate: float = float("nan")
     n_resample: int = 0
     status: int = 0      # OR of the filter status bits of every call (1 = event cap hit, 2 = all weights zero)
+    migration: Optional[dict] = None  # distributed runs: populations this rank received over all resamplings, block size
 
 
 def compute_ess(w: np.ndarray) -> float:
@@ -204,7 +205,8 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
         mu, cv = compute_is_mu_covar(theta, w)
         out = ImportanceSample(mu, cv, theta, w, time.perf_counter_ns() - start, -bme,
                                acceptance_rate=(k_log[1] / k_log[0]) if k_log[0] else float("nan"), n_resample=n_resample,
-                               status=int(getattr(bank, "status_accum", 0)))
+                               status=int(getattr(bank, "status_accum", 0)),
+                           migration={"rows_received": sb.total_rows_received, "block": sb.hi - sb.lo} if distributed else None)
         if verbose:
             ar = f"{100.0 * out.acceptance_rate:.3g}" if k_log[0] else "n/a"
             print(f"- finished in {out.run_time / 1e9:.1f} seconds (AR = {ar}%)")

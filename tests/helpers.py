@@ -22,6 +22,15 @@ class OraclePop:
     def import_state(self, t):
         self.pops = [t[i].numpy().copy() for i in range(t.shape[0])]
 
+    def export_rows(self, rows):
+        import torch
+        S = self.pops[0].shape[1]
+        return torch.from_numpy(np.stack([self.pops[r] for r in rows]) if len(rows) else np.zeros((0, self.P, S), dtype=np.int64))
+
+    def import_rows(self, slots, rows):
+        for s, r in zip(slots, rows):
+            self.pops[int(s)] = r.numpy().copy()
+
     def close(self):
         pass
 

@@ -77,6 +77,37 @@ def test_single_process_is_identity(dp):
     assert np.array_equal(out, [3.0 + 0, 4.0 + 0])
 
 
+def test_migration_plan_moves_each_population_once_per_destination():
+    """The plan of the theta-level migration, executed on plain arrays: equals nidx-gathering the whole bank, while
+    no rank receives more rows than its block has slots."""
+    from dpomp_amd import parallel
+    rng = np.random.default_rng(3)
+    for N, world in ((51, 2), (50, 3), (8, 8), (5, 8), (512, 8)):
+        bank = np.arange(N) * 10  # population b is the number 10 b
+        for trial in range(4):
+            w = rng.random(N) ** (1 + 3 * trial)
+            nidx = np.sort(rng.choice(N, size=N, p=w / w.sum()))  # systematic resampling gives sorted ancestors
+            if trial == 3:
+                nidx = rng.permutation(nidx)                       # but nothing relies on it
+            plans = [parallel.migration_plan(nidx, N, world, r) for r in range(world)]
+            bounds = [parallel.shard_bounds(N, world, r) for r in range(world)]
+            for r, (lo, hi) in enumerate(bounds):
+                p = plans[r]
+                assert p["recv_counts"].sum() <= hi - lo and p["recv_counts"][r] == 0 and p["send_counts"][r] == 0
+                # what arrives: every other rank's send list for r, in rank order
+                recv = []
+                for q in range(world):
+                    if q != r:
+                        off = plans[q]["send_counts"][:r].sum()
+                        rows = plans[q]["send_rows"][off:off + plans[q]["send_counts"][r]]
+                        assert len(rows) == p["recv_counts"][q] and len(np.unique(rows)) == len(rows)
+                        recv.extend(bank[bounds[q][0] + rows])
+                recv = np.array(recv, dtype=np.int64)
+                new = bank[lo:hi][p["local_anc"]]
+                new[p["remote_slots"]] = recv[p["remote_pick"]]
+                assert np.array_equal(new, bank[nidx[lo:hi]])
+
+
 def _smc2_worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, ROOT)
@@ -93,18 +124,20 @@ def _smc2_worker(rank, world, port, out_dir):
     theta0 = prior.rand(np.random.default_rng(5), 51)  # odd count: blocks of 26 and 25
     out = dp.run_pibis(OracleBank(dp, orc, model, y), prior, theta0, 0.3, True, 1.002, 64, seed=9,
                        rng=np.random.default_rng(11), verbose=False, distributed=True)
-    np.savez(os.path.join(out_dir, f"smc2_rank{rank}.npz"), bme=out.bme, theta=out.theta, weight=out.weight, nres=out.n_resample)
+    np.savez(os.path.join(out_dir, f"smc2_rank{rank}.npz"), bme=out.bme, theta=out.theta, weight=out.weight, nres=out.n_resample,
+             rows_received=out.migration["rows_received"], block=out.migration["block"])
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_distributed_smc2_equals_single_process(tmp_path, dp, orc):
-    """SMC^2 with the theta-particles sharded over 2 ranks (populations migrate at theta-level resampling)
-    walks exactly the path of the single-process run."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_smc2_equals_single_process(tmp_path, dp, orc, world):
+    """SMC^2 with the theta-particles sharded over 2 / 3 ranks (populations migrate at theta-level resampling, each
+    rank receiving at most its block's worth per resampling) walks exactly the path of the single-process run."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import OracleBank
-    mp.spawn(_smc2_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_smc2_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     y = dp.get_observations(os.path.join(ROOT, "tests", "golden", "pooley.csv"))
     model = dp.generate_model("SIS", [100, 1])
     prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
@@ -112,9 +145,10 @@ def test_distributed_smc2_equals_single_process(tmp_path, dp, orc):
     ref = dp.run_pibis(OracleBank(dp, orc, model, y), prior, theta0, 0.3, True, 1.002, 64, seed=9,
                        rng=np.random.default_rng(11), verbose=False)
     assert ref.n_resample >= 1
-    for r in range(2):
+    for r in range(world):
         got = np.load(tmp_path / f"smc2_rank{r}.npz")
         assert np.array_equal(got["bme"], ref.bme) and np.array_equal(got["theta"], ref.theta) and np.array_equal(got["weight"], ref.weight)
+        assert 0 < got["rows_received"] <= ref.n_resample * got["block"]  # never the whole bank (51 per resampling)
 
 
 def _pmmh_worker(rank, world, port, out_dir):
