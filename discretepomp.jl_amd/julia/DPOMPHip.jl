@@ -74,6 +74,28 @@ mutable struct Filter
     keep::Any          # arrays the descriptor points to
     n_params::Int
     n_obs::Int
+    pops::Vector{WeakRef}   # live populations: freed before the handle (finalizers run in no particular order)
+end
+
+# The structs above must have the layout the library was compiled with.
+function __init__()
+    for (which, T) in ((0, ModelDescC), (1, RateTermC), (2, ObsModelC))
+        n = ccall((:dpomp_abi_sizeof, LIB), Cint, (Cint,), which)
+        n == sizeof(T) || error("DPOMPHip: sizeof($T) = $(sizeof(T)) but libdpomp_hip.so says $n (ABI mismatch)")
+    end
+end
+
+"Frees the populations that are still alive, then the handle.  Idempotent; also the finalizer."
+function close!(f::Filter)
+    f.handle == C_NULL && return
+    for w in f.pops
+        p = w.value
+        p === nothing || free!(p)
+    end
+    empty!(f.pops)
+    ccall((:dpomp_destroy, LIB), Cvoid, (Ptr{Cvoid},), f.handle)
+    f.handle = C_NULL
+    return
 end
 
 check(h, rc) = rc == 0 ? nothing :
@@ -112,15 +134,15 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
     desc = Ref(ModelDescC(1, S, E, K, freq_dep ? b_fd : b_dd, model.t0_index,
                           pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
                           pad(terms, MAX_EVENTS, zero_term),
-                          ObsModelC(user_obs ? 100 : 1, mask(seq), mask(seq), 0, obs_error),
+                          ObsModelC(1 #= DPOMP_OBS_GAUSSIAN =#, mask(seq), mask(seq), 0, obs_error),
                           length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve obs_time obs_id obs_value begin
         rc = ccall((:dpomp_create, LIB), Cint, (Ref{ModelDescC}, Cint, Ref{Ptr{Cvoid}}), desc, device, h)
     end
     rc == 0 || error("dpomp_create: ", unsafe_string(ccall((:dpomp_last_global_error, LIB), Cstring, ())))
-    f = Filter(h[], (obs_time, obs_id, obs_value), K, length(y))
-    finalizer(x -> ccall((:dpomp_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    f = Filter(h[], (obs_time, obs_id, obs_value), K, length(y), WeakRef[])
+    finalizer(close!, f)
     return f
 end
 
@@ -157,8 +179,8 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
                    desc, device, rate_source, h)
     end
     rc == 0 || error("dpomp_create_with_source: ", unsafe_string(ccall((:dpomp_last_global_error, LIB), Cstring, ())))
-    f = Filter(h[], (obs_time, obs_id, obs_value), n_params, length(y))
-    finalizer(x -> ccall((:dpomp_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), f)
+    f = Filter(h[], (obs_time, obs_id, obs_value), n_params, length(y), WeakRef[])
+    finalizer(close!, f)
     return f
 end
 
@@ -235,8 +257,18 @@ function Population(f::Filter, B::Integer, P::Integer)
     p = Ref{Ptr{Cvoid}}(C_NULL)
     check(f.handle, ccall((:dpomp_pop_alloc, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), f.handle, B, P, p))
     pop = Population(f, p[], B, P)
-    finalizer(x -> ccall((:dpomp_pop_free, LIB), Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}), x.f.handle, x.ptr), pop)
+    push!(f.pops, WeakRef(pop))
+    finalizer(free!, pop)
     return pop
+end
+
+"Frees the device buffers (idempotent; a population whose filter is already closed has been freed by it)."
+function free!(pop::Population)
+    if pop.ptr != C_NULL && pop.f.handle != C_NULL
+        ccall((:dpomp_pop_free, LIB), Cvoid, (Ptr{Cvoid}, Ptr{Cvoid}), pop.f.handle, pop.ptr)
+    end
+    pop.ptr = C_NULL
+    return
 end
 
 "partial_log_likelihood!(pop[p], model, θ[:,p], fn_rs, essc, ymin, ymax) for every p at once (src/hmm_ibis.jl:53-56)."
@@ -285,6 +317,130 @@ function download(pop::Population, b::Integer, S::Integer)
     GC.@preserve out check(pop.f.handle, ccall((:dpomp_pop_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Int64}),
                                                pop.f.handle, pop.ptr, b - 1, out))
     return out
+end
+
+"""
+    run_pibis(f, model, theta, ess_rs_crit, ind_prop, alpha, np; n_props=1, seed=1) -> ImportanceSample
+
+SMC^2 (Chopin 2013) with the loop structure, bookkeeping and quirks of `DiscretePOMP.run_pibis`
+(src/hmm_ibis.jl:12-135), every per-theta-particle loop of which becomes ONE batched call on device-resident
+populations:
+
+    :53-56   gx[p] = partial_log_likelihood!(pop[p], ...)   -> partial_log_likelihood!(pops, theta, obs_min, obs_i)
+    :71-75   pop2[p] .= pop[nidx[p]]                        -> gather!(pops, nidx)
+    :90-100  pop_f = zeros(...); two partial_log_likelihood! -> the proposals of ALL particles drawn first, their
+                                                               filters run as one batch on a second bank `pops_f`
+    :108     pop[p] .= pop_f                                -> take!(pops, pops_f, accepted)
+
+Host-side pieces are the reference's own functions (`rs_systematic`, `compute_is_mu_covar!`, `get_prop_density`,
+`get_mv_param`, `compute_ess`, `ImportanceSample`).  One deliberate difference: with conditional proposals the
+reference adapts `tj` inside the sweep over particles; here a sweep's proposals are drawn with the `tj` of its start
+and the accumulated factor is applied afterwards (with `ind_prop = true`, the default, there is no difference).
+"""
+function run_pibis(f::Filter, model, theta::Array{Float64,2}, ess_rs_crit::Float64, ind_prop::Bool, alpha::Float64,
+                   np::Int64; n_props = 1, seed::Integer = 1)
+    DP = DiscretePOMP
+    outer_p = size(theta, 2)
+    start_time = time_ns()
+    ess_crit = ess_rs_crit * outer_p
+    theta = copy(theta)
+    w = ones(outer_p)
+    aw = [DP.Distributions.logpdf(model.prior, theta[:, i]) for i in 1:outer_p]
+    pops = Population(f, outer_p, np)       # pop[p], :26-30
+    pops_f = Population(f, outer_p, np)     # pop_f of every particle's proposal, :90
+    mu = zeros(size(theta, 1))
+    cv = zeros(size(theta, 1), size(theta, 1))
+    k_log = zeros(Int64, 2)
+    bme = zeros(2)
+    propd = DP.Distributions.MvNormal(Matrix{Float64}(DP.LinearAlgebra.I, size(theta, 1), size(theta, 1)))
+    tj = 0.2
+    calls = Ref(UInt64(0))
+    next_seed() = (calls[] += 1; UInt64(seed) * 0x9E3779B97F4A7C15 + calls[])   # the reference advances a global RNG instead
+    obs_min = 1
+    for obs_i in 1:f.n_obs
+        model.obs_data[obs_i].obs_id > 0 || continue
+        gx = partial_log_likelihood!(pops, theta, obs_min, obs_i; seed = next_seed())     # :53-56
+        aw .+= gx
+        gx .= exp.(gx)
+        lml = log(sum(w .* gx) / sum(w))                                                   # :60
+        bme[1] += lml
+        w .*= gx
+        DP.compute_is_mu_covar!(mu, cv, theta, w)
+        if DP.compute_ess(w) < ess_crit                                                    # :65
+            propd = DP.get_prop_density(cv, propd)
+            nidx = DP.rs_systematic(w)                                                     # :70
+            theta = theta[:, nidx]
+            aw = aw[nidx]
+            gather!(pops, Vector{Int64}(nidx))                                             # :74
+            mlr = DP.Statistics.mean(gx[nidx]) * exp(lml)
+            k_log[1] += outer_p
+            mtd_gx = gx[nidx]
+            for mki in 1:n_props                                                           # :85
+                theta_f = similar(theta)
+                for p in 1:outer_p                                                         # :87
+                    theta_f[:, p] .= ind_prop ? DP.get_mv_param(propd, 1.0, mu) : DP.get_mv_param(propd, tj, theta[:, p])
+                end
+                prtf = [DP.Distributions.logpdf(model.prior, theta_f[:, p]) for p in 1:outer_p]
+                ok = prtf .!= -Inf
+                any(ok) || continue
+                th_run = copy(theta_f)
+                th_run[:, .!ok] .= theta[:, .!ok]   # proposals outside the prior run a harmless theta and are ignored
+                if obs_i == 1                                                              # :92-94
+                    gx_f = partial_log_likelihood!(pops_f, th_run, 1, 1; seed = next_seed())
+                    aw_f = copy(gx_f)
+                else                                                                       # :95-100
+                    aw_f = partial_log_likelihood!(pops_f, th_run, 1, obs_i - 1; seed = next_seed())
+                    gx_f = partial_log_likelihood!(pops_f, th_run, obs_i, obs_i; seed = next_seed())
+                    aw_f .+= gx_f
+                end
+                aw_f .+= prtf
+                take = zeros(Int64, outer_p)
+                n_acc = 0
+                for p in 1:outer_p
+                    ok[p] || continue
+                    if exp(aw_f[p] - aw[p]) > rand()                                       # :104 (no proposal-density ratio, as there)
+                        mtd_gx[p] = exp(gx_f[p])
+                        theta[:, p] .= theta_f[:, p]
+                        aw[p] = aw_f[p]
+                        take[p] = p
+                        n_acc += 1
+                    end
+                end
+                n_acc > 0 && take!(pops, pops_f, take)                                     # :108
+                k_log[2] += n_acc
+                tj *= alpha^n_acc * 0.999^(count(ok) - n_acc)                              # :110-112, per sweep
+            end
+            bme[2] += log(mlr / DP.Statistics.mean(mtd_gx))                                # :118
+            w .= 1
+        else
+            bme[2] += log(sum(w .* gx) / sum(w))                                           # :122
+        end
+        obs_min = obs_i + 1
+    end
+    DP.compute_is_mu_covar!(mu, cv, theta, w)
+    free!(pops); free!(pops_f)
+    output = DP.ImportanceSample(mu, cv, theta, w, time_ns() - start_time, -bme)
+    println("- finished in ", DP.print_runtime(output.run_time), " (AR = ", round(100.0 * k_log[2] / k_log[1]; sigdigits = 3), "%)")
+    return output
+end
+
+"""
+    run_smc2_analysis(model, obs_data; np=4000, npf=200, ess_rs_crit=0.3, ind_prop=true, alpha=1.002, seed=1, kwargs...)
+
+Drop-in for `DiscretePOMP.run_smc2_analysis` (src/DiscretePOMP.jl:251-257) -- and so for the default algorithm of
+`run_ibis_analysis` (:289-302) -- with the particle filter on the GPU.  `kwargs` go to `Filter` (freq_dep, obs_error, seq, device).
+"""
+function run_smc2_analysis(model::DiscretePOMP.DPOMPModel, obs_data::Array{DiscretePOMP.Observation,1};
+                           np = 4000, npf = 200, ess_rs_crit = 0.3, ind_prop = true, alpha = 1.002, seed::Integer = 1, kwargs...)
+    f = Filter(model, obs_data; kwargs...)
+    mdl = DiscretePOMP.get_private_model(model, obs_data)     # for prior and obs_data, as the reference does (:252)
+    theta_init = rand(mdl.prior, np)
+    println("Running: ", np, "-particle SMC^2 analysis (model: ", model.model_name, ")")
+    try
+        return run_pibis(f, mdl, theta_init, ess_rs_crit, ind_prop, alpha, npf; seed = seed)
+    finally
+        close!(f)
+    end
 end
 
 end # module
