@@ -177,7 +177,7 @@ struct dpomp_pop {
     int32_t* offs = nullptr;
     unsigned long long* blocksum = nullptr;
     unsigned long long* blockprefix = nullptr;
-    int32_t* tile_end = nullptr;           // [B][nblk]
+    int32_t* tile_end = nullptr;           // [B][Pp/256] first_parent map of the last systematic resampling
     double* posw = nullptr;                // [B][Pp]   (allocated on first use of resampler 2 / 3)
     double* tile_end_pos = nullptr;        // [B][nblk]
     double* rsu = nullptr;                 // [B]
@@ -421,7 +421,7 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->offs, (size_t)B * p->Pp * sizeof(int32_t));
     DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
-    DPOMP_ALLOC(p->tile_end, (size_t)B * p->nblk * 4);
+    DPOMP_ALLOC(p->tile_end, (size_t)B * (p->Pp / kParentBlock) * 4);
     DPOMP_ALLOC(p->rsu, (size_t)B * 8);
     DPOMP_ALLOC(p->ctl, p->ctl_bytes);
     pop_bind_ctl(p);
@@ -433,6 +433,11 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
         hipHostMalloc((void**)&p->h_theta, (size_t)B * p->K * 8, hipHostMallocDefault) != hipSuccess) {
         pop_release(p);
         return fail(h, DPOMP_ENOMEM, "hipHostMalloc of the staging buffers failed");
+    }
+    // padding lanes [P, Pp) of the state rows are never written by the filter: give them a defined value once
+    if (hipMemset(p->state[0], 0, n_state * sizeof(int32_t)) != hipSuccess || hipMemset(p->state[1], 0, n_state * sizeof(int32_t)) != hipSuccess) {
+        pop_release(p);
+        return fail(h, DPOMP_EDEVICE, "hipMemset of the new population failed");
     }
     *out = p;
     return DPOMP_OK;
@@ -455,7 +460,7 @@ size_t pop_carve(dpomp_handle* h, dpomp_pop* p, unsigned char* base) {
     p->offs = reinterpret_cast<int32_t*>(take(B * p->Pp * 4));
     p->blocksum = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
     p->blockprefix = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
-    p->tile_end = reinterpret_cast<int32_t*>(take(B * p->nblk * 4));
+    p->tile_end = reinterpret_cast<int32_t*>(take(B * (p->Pp / kParentBlock) * 4));
     p->rsu = reinterpret_cast<double*>(take(B * 8));
     p->ctl = reinterpret_cast<char*>(take(p->ctl_bytes));
     p->wtot = reinterpret_cast<unsigned long long*>(take(B * 8));
@@ -521,6 +526,18 @@ hipError_t clear_device(hipStream_t st, void* ptr, size_t bytes) {
 
 hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a);
 
+// End of a filter call: the first `bytes` of the control block onto the host (asynchronous copy into the pinned staging
+// buffer, one synchronisation).  Tried instead and not kept: a last kernel that stores the results straight into the
+// pinned buffer and raises a flag the host polls -- 4 us less on a call in which nothing happens, nothing measurable on
+// a real filter, slower with many launches in flight.
+int finish_call(dpomp_handle* h, dpomp_pop* p, hipStream_t st, size_t bytes) {
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    collect_timings_if_many(h);
+    return DPOMP_OK;
+}
+
 // The sequencer.  ymin/ymax 1-based as in the reference.
 int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, int ymax, uint64_t seed,
                 int64_t seg_base, uint32_t domain, double* out_ll, uint32_t* out_status,
@@ -551,9 +568,19 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         if (fresh || ymin == 1) HIPCHK(h, clear_device(st, p->carry[p->carry_cur], (size_t)B * 4));
         if (fresh) HIPCHK(h, clear_device(st, p->carry[p->carry_cur ^ 1], (size_t)B * 4));
     }
-    memcpy(p->h_theta, theta, (size_t)B * p->K * 8);
-    HIPCHK(h, hipMemcpyAsync(p->theta, p->h_theta, (size_t)B * p->K * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(h, clear_device(st, p->ctl, p->ctl_bytes));
+    {   // first kernel of the call: clear the control block; a small batch's parameters ride in its arguments
+        const int n_theta = (int)(B * p->K);
+        ThetaInline ti{};
+        if (n_theta <= kThetaInline) {
+            memcpy(ti.v, theta, (size_t)n_theta * 8);
+        } else {
+            memcpy(p->h_theta, theta, (size_t)n_theta * 8);
+            HIPCHK(h, hipMemcpyAsync(p->theta, p->h_theta, (size_t)n_theta * 8, hipMemcpyHostToDevice, st));
+        }
+        const int64_t words = (int64_t)(p->ctl_bytes / 4);
+        hipLaunchKernelGGL(k_begin, dim3((unsigned)((words + kBlock - 1) / kBlock)), block, 0, st, reinterpret_cast<uint32_t*>(p->ctl),
+                           words, p->theta, ti, n_theta <= kThetaInline ? n_theta : 0);
+    }
 
     // A filter that fits one workgroup runs whole in ONE kernel (all observations ymin..ymax, everything between
     // the steps kept in LDS / registers) -- the regime of the reference's defaults (200 particles per filter).
@@ -591,21 +618,28 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         }
         p->initialised = true;
         HIPCHK(h, hipGetLastError());
-        const char* const result_data = p->h_result;  // (the per-interval counters behind sched_offset are not used here)
-        HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->sched_offset, hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        collect_timings_if_many(h);
+        if (int rc = finish_call(h, p, st, p->sched_offset)) return rc;  // (the per-interval counters are not used here)
+        const char* const result_data = p->h_result;
         if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
         memcpy(&h->last_events, result_data + (size_t)B * 8, 8);
         if (out_status) memcpy(out_status, result_data + (size_t)B * 8 + 8, (size_t)B * 4);
         return DPOMP_OK;
     }
 
-    if (ymin == 1) {  // pop[i,:] .= initial_condition  (:41-45)
-        timed_launch(h, KID_INIT, k_init, grid_tiles, block, 0, st, h->dm, p->state[p->cur], p->Pp);
-        p->initialised = true;
-    }
+    if (ymin == 1) p->initialised = true;  // pop[i,:] .= initial_condition (:41-45) happens inside the first propagation
     double t_prev = (ymin == 1) ? 0.0 : h->obs_time[ymin - 2];  // :45-47
+
+    // Schedule of the propagation towards observation k (0-based): enough waves must remain to fill 256 CUs x 4 SIMDs
+    // several times over.  Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue
+    // slots are taken by other waves) unless the interval kept the lanes busy last time; below that the plain kernel
+    // wins by 10-15 % (tools/latency_probe.py).  lane_util = -1 (not measured yet) -> compaction.
+    auto pick_variant = [&](int k) {
+        if (h->force_rpl) return h->force_rpl;
+        return (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
+    };
+    // A systematic resampling that is followed by another propagation in this call is not carried out by a gather pass:
+    // the next propagation reads every slot's state from its ancestor (PropArgs::parents) and writes to the other buffer.
+    bool pending_gather = false;
 
     for (int obs_i = ymin; obs_i <= ymax; ++obs_i) {  // :54
         const int k = obs_i - 1;
@@ -613,6 +647,17 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         PropArgs a;
         a.m = h->dm;
         a.state = p->state[p->cur];
+        a.parents = nullptr;
+        a.offs = nullptr;
+        a.first_parent = nullptr;
+        a.noresample = nullptr;
+        if (pending_gather) {
+            a.parents = p->state[p->cur];
+            a.state = p->state[p->cur ^ 1];
+            a.offs = p->offs;
+            a.first_parent = p->tile_end;
+            a.noresample = adaptive ? p->noresample : nullptr;
+        }
         a.logw = p->logw;
         a.theta = p->theta;
         a.segmax = p->segmax + (size_t)k * B;
@@ -628,22 +673,21 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.t_max = h->obs_time[k];
         a.ysum = h->ysum[k];
         a.use_theta_t0 = (obs_i == 1 && h->dm.t0_index > 0) ? 1 : 0;
+        a.from_x0 = obs_i == 1 ? 1 : 0;
         a.want_weight = weighted ? 1 : 0;
         a.carry_in = adaptive ? p->carry[p->carry_cur] : nullptr;
         a.yval = h->d_obs_val + (size_t)k * h->n_obs_values;
         a.n_yval = h->n_obs_values;
         a.sched = reinterpret_cast<unsigned long long*>(p->ctl + p->sched_offset) + kSchedStride * (size_t)k;
         {
-            // Particles per lane: enough waves must remain to fill 256 CUs x 4 SIMDs several times over.
-            // Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue slots are
-            // taken by other waves); below that the plain kernel wins by 10-15 % (tools/latency_probe.py).
-            int rpl = h->force_rpl;
-            if (rpl == 0)
-                rpl = (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil)
-                          ? kDefaultPropVariant : 1;  // lane_util = -1 (not measured yet) -> compaction
+            const int rpl = pick_variant(k);
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             // iterate_particles! :56
             HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
+            if (pending_gather) {
+                p->cur ^= 1;
+                pending_gather = false;
+            }
         }
         if (record_states)
             HIPCHK(h, hipMemcpyAsync(record_states + (size_t)k * B * p->S * p->Pp, p->state[p->cur],
@@ -715,6 +759,16 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                     t_prev = h->obs_time[k];
                     continue;
                 }
+                // old_p .= pop; fn_rs(pop, old_p, cum_weight)  :66-67 -- inside the next propagation of this call if there is
+                // one (the LDS-queue schedules load whole chunks and keep the separate pass)
+                if (obs_i < ymax) {
+                    const int next = pick_variant(k + 1);
+                    if (next != 2 && next != 4) {
+                        pending_gather = true;
+                        t_prev = h->obs_time[k];
+                        continue;
+                    }
+                }
                 GatherArgs g;
                 g.src = p->state[p->cur];
                 g.dst = p->state[p->cur ^ 1];
@@ -734,11 +788,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         }
         t_prev = h->obs_time[k];  // :72
     }
-    HIPCHK(h, hipGetLastError());
+    if (int rc = finish_call(h, p, st, p->ctl_result_bytes)) return rc;
     const char* const result_data = p->h_result;
-    HIPCHK(h, hipMemcpyAsync(p->h_result, p->ctl, p->ctl_result_bytes, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    collect_timings_if_many(h);
     if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
     memcpy(&h->last_events, result_data + (size_t)B * 8, 8);
     if (out_status) memcpy(out_status, result_data + (size_t)B * 8 + 8, (size_t)B * 4);
@@ -1125,7 +1176,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         }
     }
     {   // pinned staging of dpomp_pf_loglik_static, sized for its largest call
-        const size_t n_res = (size_t)DPOMP_STATIC_MAX_SEGMENTS * 12 + 16 + (size_t)d->n_obs * kSchedStride * 8;
+        const size_t n_res = (size_t)DPOMP_STATIC_MAX_SEGMENTS * 12 + 16 + (size_t)d->n_obs * kSchedStride * 8 + 64;
         if (hipHostMalloc((void**)&h->static_h_result, n_res, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void**)&h->static_h_theta, (size_t)DPOMP_STATIC_MAX_SEGMENTS * DPOMP_MAX_PARAMS * 8, hipHostMallocDefault) != hipSuccess) {
             rc = fail(nullptr, DPOMP_ENOMEM, "hipHostMalloc of the static staging buffers failed");

@@ -65,12 +65,25 @@ struct PropArgs {
     double t_prev, t_max;
     long long ysum;
     int32_t use_theta_t0;  // first interval of a ymin == 1 call with t0_index > 0
+    int32_t from_x0;       // first interval of a ymin == 1 call: every particle starts at the initial condition
+                           // (pop[i,:] .= initial_condition, hmm_particle_filter.jl:42-44) instead of being loaded
     int32_t want_weight;
     const int32_t* carry_in;  // [B] ESS-adaptive mode: 1 = add the carried log-weight (still in logw) to the new one
     const long long* yval;    // [V] Observation.val of this observation (user observation models)
     int32_t n_yval;
     unsigned long long* sched;  // this interval's counters, see sched_add()
+    // Resampling fused into the load (systematic resampling of the previous observation): when `parents` is set, slot p
+    // starts from the state of its ancestor in `parents` -- pop[i,:] = old_p[j_i,:] (hmm_pf_resample.jl:38) without a
+    // separate gather pass -- and the propagated state goes to `state` (the other buffer).
+    const int32_t* parents;       // [B][S][Pp] population before resampling, or null
+    const int32_t* offs;          // [B][Pp]    offspring boundaries N_j of that resampling
+    const int32_t* first_parent;  // [B][Pp/256] parent block (of 256) of the first slot of every 256-slot block
+    const int32_t* noresample;    // [B] or null: 1 = the population was kept (ESS-adaptive mode): slot p descends from p
 };
+
+constexpr int kParentBlock = 256;                       // granularity of the first_parent map (= slots per propagate workgroup)
+constexpr int kStageBlocks = 6;                         // parent blocks a workgroup stages in LDS for the ancestor search
+constexpr int kStageSlots = kStageBlocks * kParentBlock;  // 1536 boundaries = 6 KB
 // The workgroups of a launch publish their maximum log-weight into one word per filter.  Thousands of atomics on one
 // address serialise at the L2 (~9 ns each: 37 us for the 4096 workgroups of a 2^20-particle filter, most of a launch
 // in which little happens), but the maximum is established by the first few workgroups: read it first and only the
@@ -361,6 +374,70 @@ __global__ __launch_bounds__(kBlock) void k_zero(uint32_t* dst, int64_t words) {
     if (i < words) dst[i] = 0u;
 }
 
+// ---- k_begin: the first kernel of a filter call -- clears the control block and, for small batches, stores the
+// parameter vectors that arrived as kernel arguments (no host-to-device copy in front of the call) -----------
+constexpr int kThetaInline = 32;  // doubles
+struct ThetaInline {
+    double v[kThetaInline];
+};
+__global__ __launch_bounds__(kBlock) void k_begin(uint32_t* ctl, int64_t words, double* theta_dst, ThetaInline th, int n_theta) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < words) ctl[i] = 0u;
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_theta) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < kThetaInline; ++k)  // (constant indices: the argument stays in SGPRs)
+            if (k == (int)threadIdx.x) v = th.v[k];
+        theta_dst[threadIdx.x] = v;
+    }
+}
+
+template <class Ptr>
+__device__ __forceinline__ int first_greater(Ptr N, int n, int i) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (N[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// Ancestor of slot p under systematic resampling = first j with N_j > p (rsp_systematic's `while u[i] > cw[j]`,
+// hmm_pf_resample.jl:33-37, solved per slot).  N is monotone, so the 256 slots of a workgroup descend from a contiguous
+// window of parent blocks [first_parent[w], first_parent[w+1]] (written by k_offsets).  The workgroup stages that window
+// of N in LDS (`stage`, kStageSlots ints, coalesced) and every lane searches there (11 LDS steps); a wider window (very
+// uneven weights) is searched in L2 with a bounded binary search.  All threads of the workgroup must call this
+// (barriers); returns the ancestor of thread's slot (0 for lanes past P).
+__device__ __forceinline__ int find_ancestor(const PropArgs& a, int b, int p, bool valid, int32_t* stage) {
+    if (a.noresample && a.noresample[b]) return valid ? p : 0;  // (workgroup-uniform)
+    const int nblk = (int)(a.Pp / kParentBlock);
+    const int32_t* N = a.offs + (int64_t)b * a.Pp;
+    const int32_t* fp = a.first_parent + (int64_t)b * nblk;
+    const int w = blockIdx.x;  // this workgroup's 256-slot block
+    const int last = (a.P - 1) / kParentBlock;
+    const int tlo = fp[w];
+    const int thi = (w + 1 <= last) ? fp[w + 1] : last;  // ancestors are monotone in the slot index
+    const int nb = thi - tlo + 1;
+    int j;
+    if (nb <= kStageBlocks) {
+        const int M = nb * kParentBlock;
+        for (int t = threadIdx.x; t < M; t += kBlock) stage[t] = N[(int64_t)tlo * kParentBlock + t];
+        __syncthreads();
+        int lo = 0;  // number of staged boundaries <= p
+#pragma unroll
+        for (int step = 1024; step > 0; step >>= 1) {
+            const int mid = lo + step;
+            if (mid <= M && stage[mid - 1] <= p) lo = mid;
+        }
+        j = tlo * kParentBlock + lo;
+        __syncthreads();  // the staging area is reused by the caller
+    } else {
+        const int base = tlo * kParentBlock;
+        j = valid ? base + first_greater(N + base, min(nb * kParentBlock, a.P - base), p) : 0;
+    }
+    return valid ? min(j, a.P - 1) : 0;
+}
+
 // ---- k_init: pop[i,:] .= initial_condition   (hmm_particle_filter.jl:42-44) -----------------
 __global__ __launch_bounds__(kBlock) void k_init(DevModel m, int32_t* state, int64_t Pp) {
     const int64_t b = blockIdx.y;
@@ -392,12 +469,19 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     __shared__ double s_log[kLogTableSize][2];  // dlog table: one ds_read_b128 per event
+    __shared__ int32_t s_stage[kStageSlots];    // offspring boundaries of the parents' window (find_ancestor)
     for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    const int32_t* ld = st;  // where this slot's starting state is read from
+    int pj = p;
+    if (a.parents) {         // resampling fused into the load
+        ld = a.parents + (int64_t)b * s_real * a.Pp;
+        pj = find_ancestor(a, b, p, valid, s_stage);
+    }
     __syncthreads();
 
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? a.m.x0[s] : ld[(int64_t)s * a.Pp + pj]) : 0;
 
     double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
@@ -505,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         if (idx < cnt) {
             const int p = base + idx;
 #pragma unroll
-            for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
+            for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? (a.from_x0 ? a.m.x0[s] : st[(int64_t)s * a.Pp + p]) : 0;
             const StreamSeed r = stream_seed(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
             s_seed[idx] = make_uint4(r.w0, r.w1, r.w2, r.w3);
         }
@@ -678,10 +762,17 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
+    static_assert(kStageSlots * 4 <= kCtxBytes * kLive, "the ancestor search stages its window in the compaction buffer");
+    const int32_t* ld = st;  // where this slot's starting state is read from
+    int pj = p;
+    if (a.parents) {         // resampling fused into the load (the compaction buffer is free until the first compaction)
+        ld = a.parents + (int64_t)b * s_real * a.Pp;
+        pj = find_ancestor(a, b, p, valid, reinterpret_cast<int32_t*>(c_raw));
+    }
 
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? st[(int64_t)s * a.Pp + p] : 0;
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? a.m.x0[s] : ld[(int64_t)s * a.Pp + pj]) : 0;
     double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
@@ -1062,7 +1153,7 @@ struct WeightArgs {
     double* ll;                         // [B] running log-likelihood
     uint32_t* status;                   // [B]
     int32_t* offs;                      // [B][Pp]
-    int32_t* tile_end;                  // [B][nblk] first_parent: parent tile of the first slot of each output tile
+    int32_t* tile_end;                  // [B][Pp/256] first_parent: parent block (of 256) of the first slot of each 256-slot output block
     double* posw;                       // [B][Pp]   pos_j = c_j / W * P (stratified / multinomial resamplers)
     double* tile_end_pos;               // [B][nblk] pos of the last particle of each tile
     double* rsu;                        // [B] the systematic-resampling uniform of this observation (from k_wsum)
@@ -1274,16 +1365,17 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         for (int q = 0; q < kItems; ++q)
             n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
         *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
-        // Inverse map for k_gather: every 1024-slot OUTPUT tile t learns which parent tile its first slot
-        // (t * 1024) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
-        // t * 1024 writes first_parent[t] = its tile; exactly one writer per output tile, no cross-workgroup
+        // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
+        // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
+        // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
         // dependency (N_{j-1} is recomputed from the exclusive cumulative weight).
         int lo = (W == 0) ? ((i0 == 0) ? 0 : a.P) : (int)offspring_end(base + c[0] - w[0], W, a.P, r);
-        int32_t* fp = a.tile_end + (int64_t)b * a.nblk;
+        int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
+        const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
 #pragma unroll
         for (int q = 0; q < kItems; ++q) {
             const int hi = n[q];
-            for (int t = (lo + kTile - 1) / kTile; t * kTile < hi; ++t) fp[t] = blk;
+            for (int t = (lo + kParentBlock - 1) / kParentBlock; t * kParentBlock < hi; ++t) fp[t] = my_block;
             lo = hi;
         }
     } else {
@@ -1319,22 +1411,12 @@ struct GatherArgs {
 
 constexpr int kStageTiles = 4;
 
-template <class Ptr>
-__device__ __forceinline__ int first_greater(Ptr N, int n, int i) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (N[mid] > i) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-
 __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
     __shared__ __attribute__((aligned(16))) int32_t s_n[kStageTiles * kTile];
     const int b = blockIdx.y, t_out = blockIdx.x;
     const int64_t i0 = (int64_t)t_out * kTile + threadIdx.x * kItems;
     const int32_t* N = a.offs + (int64_t)b * a.Pp;
-    const int32_t* fp = a.first_parent + (int64_t)b * a.nblk;
+    const int32_t* fp = a.first_parent + (int64_t)b * (a.Pp / kParentBlock);  // per 256-slot block, in parent blocks of 256
     if (a.noresample && a.noresample[b]) {
         for (int s = 0; s < a.S; ++s) {
             const int64_t o = ((int64_t)b * a.S + s) * a.Pp + i0;
@@ -1342,8 +1424,10 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
         }
         return;
     }
-    const int tlo = fp[t_out];
-    const int thi = (t_out + 1 < a.nblk) ? fp[t_out + 1] : a.nblk - 1;  // ancestors are monotone in the slot index
+    constexpr int kPerTile = kTile / kParentBlock;
+    const int tlo = fp[t_out * kPerTile] / kPerTile;  // parent TILE of this output tile's first slot
+    const int thi = (t_out + 1 < a.nblk && (int64_t)(t_out + 1) * kTile < a.P) ? fp[(t_out + 1) * kPerTile] / kPerTile
+                                                                             : (a.P - 1) / kTile;  // ancestors are monotone in the slot index
     const int ntiles = thi - tlo + 1;
     int j[kItems];
     if (ntiles <= kStageTiles) {

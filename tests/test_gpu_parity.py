@@ -589,14 +589,22 @@ def test_sampled_profiling_brackets_every_nth_call(dp, pooley):
     for s in range(4):
         pf.loglik(theta, 4096, seed=s)
     st = pf.kernel_stats()
-    assert st["k_propagate"][0] == 2 * pf.n_obs and st["k_init"][0] == 2      # calls 0 and 2 of the four
-    assert st["k_gather"][0] == 2 * (pf.n_obs - 1) and st["k_propagate"][1] > 0.0
+    assert st["k_propagate"][0] == 2 * pf.n_obs and st["k_wsum"][0] == 2 * pf.n_obs      # calls 0 and 2 of the four
+    # the resampling gather runs inside the next propagation of the call; only a call that ENDS on a resampling
+    # observation needs the separate pass
+    assert st["k_offsets"][0] == 2 * (pf.n_obs - 1) and st["k_gather"][0] == 0 and st["k_propagate"][1] > 0.0
+    pf.set_profiling(1)
+    pop = pf.alloc_population(1, 4096)
+    pf.partial_log_likelihood(pop, theta, 1, 3, seed=2)
+    assert pf.kernel_stats()["k_gather"][0] == 1
+    pf.set_profiling(2)
+    n0 = pf.kernel_stats()["k_propagate"][0]
     pf.set_profiling(False)
     pf.loglik(theta, 4096, seed=9)
-    assert pf.kernel_stats()["k_propagate"][0] == 2 * pf.n_obs
+    assert pf.kernel_stats()["k_propagate"][0] == n0
     pf.set_profiling(True)
     pf.loglik(theta, 4096, seed=9)
-    assert pf.kernel_stats()["k_propagate"][0] == 3 * pf.n_obs
+    assert pf.kernel_stats()["k_propagate"][0] == n0 + pf.n_obs
     with pytest.raises(dp.DpompError):
         pf._check(pf._lib.dpomp_get_lane_utilisation(pf._h, pf.n_obs + 1, __import__("ctypes").byref(__import__("ctypes").c_double())))
     pf.close()
