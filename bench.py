@@ -23,7 +23,8 @@ sys.path.insert(0, ROOT)
 POOLEY = [(20.0, [0, 18]), (40.0, [0, 65]), (60.0, [0, 70]), (80.0, [0, 66]), (100.0, [0, 67])]  # data/pooley.csv
 THETA = [0.003, 0.1]
 EXACT_LL = -15.6873794556  # exact CTMC forward algorithm (oracle/exact_sis.py)
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X: 8.0 TB/s HBM3E spec
+HBM_MEASURED_COPY_GBS = 6290.0  # measured float4-copy rate of the chip (79 % of spec): the practical roof
 # VALU-issue ceiling of k_propagate: the SIS event loop is 72 VALU instructions per event (ISA of
 # k_propagate_c<RSir<2>,32>: 2 x 14 stream + uniform, 17 log, 10 division + range test, 6 rates, the rest event
 # choice, state update, clock and cap tests).  Measured issue cost per wave64 instruction on gfx950
@@ -36,13 +37,25 @@ VALU_CEILING_EVENTS_PER_S = 1024 * 2.4e9 * 64 / VALU_CYCLES_PER_WAVE_EVENT
 
 
 def algorithmic_bytes(P, S):
-    """bytes per particle-step with Int64 state as in the reference (w = 8)."""
+    """Bytes per launch with Int64 state as the reference holds it (w = 8): the accounting the metric is defined on."""
     return {
         "k_propagate": (2 * S + 1) * 8 * P,   # read state, write state, write log-weight
         "k_wsum": 8 * P,                      # normalise: read weight
         "k_scan_blocks": 0,                   # tile sums only (final observation; fused into k_offsets otherwise)
         "k_offsets": 16 * P,                  # scan: read 8 + write 8
         "k_gather": (2 * S + 1) * 8 * P,      # resample: read cum. weight + gather state + write state
+    }
+
+
+def moved_bytes(P, S):
+    """Bytes per launch the kernels really have to move: the state lives in HBM as int32, the offspring boundaries as
+    int32, log-weights as f64.  (The resampling gather of a full filter call runs inside the next k_propagate.)"""
+    return {
+        "k_propagate": (4 * S + 4 * S + 8) * P,
+        "k_wsum": 8 * P,
+        "k_scan_blocks": 0,
+        "k_offsets": (8 + 4) * P,
+        "k_gather": (4 + 4 * S + 4 * S) * P,
     }
 
 
@@ -155,14 +168,16 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the clocks of an idle GPU take ~20 filter calls (60 ms) to settle (tools/warmup_probe.py: first 20 calls
+    # 3.08 ms each, then 2.97 ms); the whole default run is still well under a second of GPU time
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--particles", type=int, default=1 << 20)
     ap.add_argument("--cpu-serial-particles", type=int, default=1 << 17)
     ap.add_argument("--cpu-parallel-particles", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="HIP-event brackets around the kernels of every n-th timed step (the markers cost GPU time)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (gloo rendezvous, rank accounting, no GPU, no filter): for the CPU test of --gpus N")
@@ -277,25 +292,43 @@ def main():
                 k["algorithmic_bytes"] = alg[name]
                 k["achieved_GBs"] = round(alg[name] / (avg_us * 1e-6) / 1e9, 1)
             kernels[name] = k
-        # dominant HBM-bound kernel of the path = the resampling gather (most bytes per launch)
-        g = kernels.get("k_gather", {})
+        # The memory-bound stage of the path: normalise (k_wsum) + scan (k_offsets); the resampling gather of a full call
+        # runs inside the next k_propagate.  The roofline object is quoted for k_offsets, the streaming kernel of that
+        # stage with the most bytes per launch, in both accountings; at this workload (16 MiB of state, 28 MiB working
+        # set) every streaming kernel is launch/latency-bound and served from L2 / Infinity Cache, so `frac` says little
+        # about HBM: the fractions at working sets beyond the 256 MiB Infinity Cache are in profiles/ (hbm_scale_probe).
+        mv = moved_bytes(P, S)
+        for name, k in kernels.items():
+            if mv.get(name):
+                k["moved_bytes"] = mv[name]
+                k["moved_GBs"] = round(mv[name] / (k["avg_us"] * 1e-6) / 1e9, 1)
+        rk = "k_offsets" if "k_offsets" in kernels else "k_wsum"
+        g = kernels.get(rk, {})
+        traffic = pmc_traffic(rk) or (None, "none")
         roofline = {
-            "kernel": "k_gather",
+            "kernel": rk,
             "bound": "hbm",
             "achieved": g.get("achieved_GBs"),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(g.get("achieved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
-            "traffic": (pmc_traffic("k_gather") or (None, None))[0],
-            "traffic_source": (pmc_traffic("k_gather") or (None, "none"))[1],
+            "traffic": traffic[0],
+            "traffic_source": traffic[1],
+            "accounting": "achieved/frac: Int64-state algorithmic bytes (the reference's layout) / kernel time; "
+                          "*_moved_bytes: bytes the kernel really moves (int32 state and boundaries)",
+            "achieved_moved_bytes": g.get("moved_GBs"),
+            "frac_moved_bytes": round(g.get("moved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
+            "peak_measured": HBM_MEASURED_COPY_GBS,
+            "frac_moved_bytes_of_peak_measured": round(g.get("moved_GBs", 0.0) / HBM_MEASURED_COPY_GBS, 4) if g else None,
+            "working_set_bytes": P * (2 * 4 * S + 8 + 4),
             "timing": f"HIP events stamped with each kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the "
                       f"launch stream), kernels of every {max(1, args.profile_every)}th timed step; the same quantity rocprofv3 reports per "
                       "dispatch (profiles/)",
-            "note": "memory-bound stage (normalise+scan+resample); k_propagate, which holds >95% of the "
-                    "time, is FP64-VALU/divergence bound (SURVEY.md 8d) and is reported under 'propagate'",
+            "note": "memory-bound stage (normalise+scan; gather fused into k_propagate); k_propagate, which holds >95% of "
+                    "the time, is FP64-VALU/divergence bound and is reported under 'propagate' with its own ceiling",
         }
         mem_us = sum(kernels[k]["avg_us"] for k in ("k_wsum", "k_scan_blocks", "k_offsets", "k_gather") if k in kernels)
-        mem_bytes = alg["k_wsum"] + alg["k_offsets"] + alg["k_gather"]
+        mem_bytes = sum(alg[k] for k in ("k_wsum", "k_offsets", "k_gather") if k in kernels)
         roofline["stage_achieved_GBs"] = round(mem_bytes / (mem_us * 1e-6) / 1e9, 1) if mem_us else None
         prop = kernels.get("k_propagate", {})
         propagate = {
@@ -309,6 +342,11 @@ def main():
         }
         if propagate.get("events_per_s"):
             propagate["valu_frac"] = round(propagate["events_per_s"] / VALU_CEILING_EVENTS_PER_S, 3)
+            # the kernel that dominates the step has neither an HBM nor an MFMA roof: its ceiling is VALU issue
+            roofline["dominant_kernel"] = {"name": "k_propagate", "share_of_kernel_time": round(
+                prop["avg_us"] * prop["launches"] / sum(k["avg_us"] * k["launches"] for k in kernels.values()), 3),
+                "bound": "valu-issue (FP64 + 64-bit integer), see 'propagate'", "achieved_events_per_s": propagate["events_per_s"],
+                "ceiling_events_per_s": round(VALU_CEILING_EVENTS_PER_S), "frac": propagate["valu_frac"]}
         mean_ll = float(np.mean(lls))
         result = {
             "metric": "particle-steps/sec",
