@@ -315,8 +315,8 @@ struct TransRows {
 // transition row -> event cap.  Returns true while the particle goes on.  FAST = the division may skip its range
 // handling (dpomp_numerics.h: div_in_range); a total outside that range -- zero included, i.e. an extinct epidemic --
 // stops the particle before anything is drawn, and the caller continues in the FAST = false loop, which is the same
-// arithmetic with the plain division.  Why a particle stopped is read off its state afterwards (stopped_on_cap,
-// stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
+// arithmetic with the plain division (finish_slow).  Why a particle stopped is read off its state afterwards
+// (stopped_on_range): a reason code or flag carried through the loop costs VALU instructions on every event.
 // The two uniforms of an event do not depend on the state, only the division by the rate total does.  They are
 // therefore drawn -- and the logarithm of the first taken -- one event AHEAD: log(u) with its LDS table read then
 // runs beside the rates -> reciprocal -> Newton chain of the current event instead of in front of the division, which
@@ -326,9 +326,9 @@ struct TransRows {
 struct Draws {
     double lu, u2;  // log of the waiting-time uniform and the event-choice uniform of the NEXT event
 };
-__device__ __forceinline__ Draws draw_ahead(Stream& rng, const double (*s_log)[2]) {
+__device__ __forceinline__ Draws draw_ahead(Stream& rng, const double (*s_log)[2], const LogRegs& lr) {
     Draws d;
-    d.lu = dlog_tab(u01(stream_next(rng)), s_log);
+    d.lu = dlog_tab(u01(stream_next(rng)), s_log, lr);
     d.u2 = u01(stream_next(rng));
     return d;
 }
@@ -336,7 +336,7 @@ __device__ __forceinline__ Draws draw_ahead(Stream& rng, const double (*s_log)[2
 template <class R, bool FAST>
 __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRows<R> rows, const double* thr,
                                                 int (&x)[R::S], double& time, const double tmax, Stream& rng, Draws& d,
-                                                int& n, const int cap, const int e_real, const double (*s_log)[2]) {
+                                                const int e_real, const double (*s_log)[2], const LogRegs& lr) {
     constexpr int S = R::S, E = R::E;
     using TW = typename TransRows<R>::TW;
     double cum[E];
@@ -350,7 +350,7 @@ __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRo
         if (tot == 0.0) return false;
     }
     const Draws now = d;
-    d = draw_ahead(rng, s_log);
+    d = draw_ahead(rng, s_log, lr);
     time = time - (FAST ? div_in_range(now.lu, tot) : now.lu / tot);
     if (time > tmax) return false;
     const double etc = now.u2 * tot;
@@ -362,11 +362,31 @@ __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRo
     }
 #pragma unroll
     for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
-    return ++n < cap;
+    return true;
 }
-__device__ __forceinline__ bool stopped_on_cap(int n, int cap) { return n >= cap; }
-// after a FAST loop returned false: neither the cap nor the clock stopped the particle, so its rate total did
-__device__ __forceinline__ bool stopped_on_range(int n, int cap, double time, double tmax) { return n < cap && !(time > tmax); }
+// Counting events costs nothing in the loop: the lanes of a wave start an interval together and every lane that is
+// still in the fast loop has executed exactly one event per iteration, so the event cap is a comparison on the
+// wave-uniform trip counter (scalar unit), and a particle's own count is read off its stream afterwards -- the stream
+// counts its draws: one pair drawn ahead at the start and one more by every call that got past the rate test, and the
+// call that overshot the observation time drew without executing.
+__device__ __forceinline__ int events_executed(const Stream& rng, double time, double tmax) {
+    const int pairs = (int)(((uint32_t)rng.n - (uint32_t)(1 + kStreamWarmup)) >> 1);
+    return pairs - 1 - (time > tmax ? 1 : 0);
+}
+// after a FAST loop returned false: the clock did not stop the particle, so its rate total did
+__device__ __forceinline__ bool stopped_on_range(double time, double tmax) { return !(time > tmax); }
+// The plain-division loop for a particle whose rate total left the fast range (zero total = extinct: returns at once):
+// runs the particle to the end of the interval with its own event count.  Returns true if the event cap stopped it.
+template <class R>
+__device__ __forceinline__ bool finish_slow(const DevModel& m, const TransRows<R> rows, const double* thr, int (&x)[R::S],
+                                            double& time, const double tmax, Stream& rng, Draws& d, const int cap,
+                                            const int e_real, const double (*s_log)[2], const LogRegs& lr) {
+    int n = events_executed(rng, time, tmax);
+    if (n >= cap) return true;
+    while (gillespie_event<R, false>(m, rows, thr, x, time, tmax, rng, d, e_real, s_log, lr))
+        if (++n >= cap) return true;
+    return false;
+}
 
 // ---- k_zero: clears counters, flags and the control block (in place of hipMemsetAsync) -------------------
 __global__ __launch_bounds__(kBlock) void k_zero(uint32_t* dst, int64_t words) {
@@ -488,16 +508,21 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
     const int e_real = R::kGeneric ? a.m.E : E;
     const TransRows<R> rows(a.m, e_real);
+    const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     const int cap = a.m.cap;
     int n = 0;
     bool capped = false;
 
     if (valid) {
-        Draws ahead = draw_ahead(rng, s_log);
-        while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
-        if (stopped_on_range(n, cap, time, tmax))
-            while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
-        capped = stopped_on_cap(n, cap);
+        Draws ahead = draw_ahead(rng, s_log, lr);
+        int it = 0;  // wave-uniform: events executed by every lane still in the loop
+        bool go;
+        do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
+        while (go && ++it < cap);
+        capped = go;  // still going after `cap` events
+        if (!go && stopped_on_range(time, tmax))
+            capped = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);
+        n = events_executed(rng, time, tmax);
     }
 
     double g = -__builtin_inf();
@@ -601,6 +626,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     const double tmax = a.t_max;
     const int e_real = R::kGeneric ? a.m.E : E;
     const TransRows<R> rows(a.m, e_real);
+    const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     const int cap = a.m.cap;
     int x[S];
 #pragma unroll
@@ -627,7 +653,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
                     for (int s = 0; s < S; ++s) x[s] = s_x[s][idx];
                     const uint4 sd = s_seed[idx];
                     rng = stream_start(StreamSeed{sd.x, sd.y, sd.z, sd.w});
-                    ahead = draw_ahead(rng, s_log);
+                    ahead = draw_ahead(rng, s_log, lr);
                     time = t_start;
                     n = 0;
                     active = true;
@@ -640,17 +666,20 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         if (active) {  // up to QCHK events, then back to the refill point (a finished lane idles for the rest of the chunk)
             int it = 0;
             bool go;
-            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-            while (go && ++it < kQueueChunk);
-            if (!go && stopped_on_range(n, cap, time, tmax)) {
-                int it2 = 0;
-                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-                while (go && ++it2 < kQueueChunk);
-            }
+            bool capped_now = false;  // (the lanes of a wave start their particles at different times: counted per lane)
+            do {
+                go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
+                if (go && ++n >= cap) {
+                    capped_now = true;
+                    go = false;
+                }
+            } while (go && ++it < kQueueChunk);
+            if (!go && !capped_now && stopped_on_range(time, tmax))
+                capped_now = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);
             if (!go) {
 #pragma unroll
                 for (int s = 0; s < S; ++s) s_x[s][cur] = x[s];
-                s_cnt[cur] = n | (stopped_on_cap(n, cap) ? (int)0x80000000 : 0);
+                s_cnt[cur] = events_executed(rng, time, tmax) | (capped_now ? (int)0x80000000 : 0);
                 active = false;
             }
         }
@@ -778,32 +807,38 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
     const int e_real = R::kGeneric ? a.m.E : E;
     const TransRows<R> rows(a.m, e_real);
+    const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     const int cap = a.m.cap;
-    int n = 0, cur = threadIdx.x;
+    int cur = threadIdx.x;
+    int ev_base = 0;      // wave-uniform: events every still-running particle of the workgroup has executed
     bool active = valid;  // particle still running
     bool parked = !valid; // final state already parked in s_res
     bool capped = false;
     __syncthreads();
-    Draws ahead = draw_ahead(rng, s_log);  // (after the barrier: reads the log table in LDS)
+    Draws ahead = draw_ahead(rng, s_log, lr);  // (after the barrier: reads the log table in LDS)
 
     for (int round = 0;; ++round) {
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
+            // every live lane of the workgroup has executed ev_base events so far (compaction moves contexts, not counts)
+            capped = false;  // (this lane may hold another particle's context than last round)
+            const int lim = min(CHK, cap - ev_base);
             int it = 0;
             bool go;
-            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-            while (go && ++it < CHK);
-            if (!go && stopped_on_range(n, cap, time, tmax)) {  // (own trip counter: keeping `it` alive per lane costs two
-                int it2 = 0;                                       //  v_mov per event in the fast loop)
-                do go = gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log);
-                while (go && ++it2 < CHK);
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
+            while (go && ++it < lim);
+            if (go && ev_base + lim >= cap) {  // (uniform) still going after `cap` events
+                capped = true;
+                go = false;
+            } else if (!go && stopped_on_range(time, tmax)) {
+                capped = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);
             }
             active = go;
-            capped = stopped_on_cap(n, cap);
         }
+        ev_base += CHK;
         if (!active && !parked) {  // once per particle, outside the hot loop
 #pragma unroll
             for (int s = 0; s < S; ++s) s_res[s][cur] = x[s];
-            s_cnt[cur] = n | (capped ? (int)0x80000000 : 0);
+            s_cnt[cur] = events_executed(rng, time, tmax) | (capped ? (int)0x80000000 : 0);
             parked = true;
         }
         const unsigned long long bal = wave_ballot(active);
@@ -834,13 +869,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
             __syncthreads();
             if (active) {  // pass 2: clock, counters, the draws made ahead
                 c_time[rank] = time;
-                c_nc[rank] = make_int2(n, cur);
+                c_nc[rank] = make_int2(0, cur);
                 c_ahead[rank] = make_double2(ahead.lu, ahead.u2);
             }
             __syncthreads();
             double moved_time = time;
             Draws moved_ahead = ahead;
-            int2 moved_nc = make_int2(n, cur);
+            int2 moved_nc = make_int2(0, cur);
             if (take) {
                 moved_time = c_time[threadIdx.x];
                 const double2 ah = c_ahead[threadIdx.x];
@@ -862,7 +897,6 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
                 rng = moved;
                 time = moved_time;
                 ahead = moved_ahead;
-                n = moved_nc.x;
                 cur = moved_nc.y;
             }
         }
@@ -964,6 +998,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     const int s_real = R::kGeneric ? a.m.S : S;
     const int e_real = R::kGeneric ? a.m.E : E;
     const TransRows<R> rows(a.m, e_real);
+    const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
     const ThetaRegs<R> th_regs(th, a.m.K);
@@ -991,11 +1026,15 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         int n = 0;
         bool capped = false;
         if (valid) {
-            Draws ahead = draw_ahead(rng, s_log);
-            while (gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
-            if (stopped_on_range(n, cap, time, tmax))
-                while (gillespie_event<R, false>(a.m, rows, thr, x, time, tmax, rng, ahead, n, cap, e_real, s_log)) {}
-            capped = stopped_on_cap(n, cap);
+            Draws ahead = draw_ahead(rng, s_log, lr);
+            int it = 0;  // wave-uniform: events executed by every lane still in the loop
+            bool go;
+            do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
+            while (go && ++it < cap);
+            capped = go;
+            if (!go && stopped_on_range(time, tmax))
+                capped = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);
+            n = events_executed(rng, time, tmax);
         }
         ev += (unsigned long long)n;
         any_cap |= capped;

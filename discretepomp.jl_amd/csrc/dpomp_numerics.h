@@ -169,10 +169,24 @@ __device__ __forceinline__ double scalar_const(double v) {
 inline double scalar_const(double v) { return v; }
 #endif
 
-DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
+// The innermost Horner step fma(r, A4, A3) has two non-inline constants; a gfx9 VALU instruction reads at most one
+// scalar operand, so with both in SGPRs the compiler copies one into a VGPR pair on every evaluation.  A loop that
+// evaluates the logarithm per iteration therefore keeps A3 in a VGPR pair of its own, set up once outside the loop.
+struct LogRegs {
+    double a3;
+};
+DPOMP_HD LogRegs log_regs() {
+    double v = 0x1.999999999999ap-3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return LogRegs{v};
+}
+
+DPOMP_HD double dlog_tab(double x, const double (*T)[2], const LogRegs& lr) {
     const double Ln2hi = 0x1.62e42fefa3800p-1, Ln2lo = 0x1.ef35793c76730p-45;
     const double A0 = -0.5, A1 = scalar_const(0x1.5555555555555p-2), A2 = scalar_const(-0.25),
-                 A3 = scalar_const(0x1.999999999999ap-3), A4 = -0x1.5555555555555p-3;
+                 A3 = lr.a3, A4 = -0x1.5555555555555p-3;
     // only the high word of bits(x) takes part in the range reduction (OFF and the exponent mask have a zero low word)
     const uint64_t ix = double_to_bits(x);
     const uint32_t hx = (uint32_t)(ix >> 32);
@@ -189,6 +203,7 @@ DPOMP_HD double dlog_tab(double x, const double (*T)[2]) {
     const double p = __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, __builtin_fma(r, A4, A3), A2), A1), A0);
     return w + __builtin_fma(r2, p, s);
 }
+DPOMP_HD double dlog_tab(double x, const double (*T)[2]) { return dlog_tab(x, T, LogRegs{0x1.999999999999ap-3}); }
 DPOMP_D double dlog(double x) { return dlog_tab(x, kLogTable); }
 
 #if defined(__HIP_DEVICE_COMPILE__)
