@@ -45,7 +45,6 @@ constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (DESIGN.m
 // utilisations of 0.75-0.87 and by 20-30 % where epidemics die out early (0.3); below 8192 waves the static kernel
 // wins by 2-7 %.
 constexpr double kCompactionBelowUtil = 0.90;
-constexpr int kGatherPosMaxTiles = 4096;  // k_gather_pos: tile_end_pos (8 B per tile) in LDS
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
@@ -551,7 +550,6 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (p->T != T || p->S != h->dm.S || p->K != h->dm.K)
         return fail(h, DPOMP_EINVAL, "population belongs to another filter (T/S/K = %d/%d/%d, this handle %d/%d/%d)", p->T, p->S, p->K, T, h->dm.S, h->dm.K);
     if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
-        if (p->nblk > kGatherPosMaxTiles) return fail(h, DPOMP_EINVAL, "resampler %d supports at most %d particles per filter", h->rs_type, kGatherPosMaxTiles * kTile);
         if (int rc = pop_ensure_pos(h, p)) return rc;
     }
     hipStream_t st = h->stream;
@@ -754,7 +752,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                     gp.obs_k = (uint32_t)k;
                     gp.seg_base = (uint32_t)seg_base;
                     gp.seed = seed;
-                    timed_launch(h, KID_GATHER, k_gather_pos, grid_tiles, block, (unsigned)((size_t)p->nblk * 8), st, gp);
+                    timed_launch(h, KID_GATHER, k_gather_pos, grid_tiles, block,
+                                 (unsigned)(p->nblk <= kGatherPosStageTiles ? (size_t)p->nblk * 8 : 0), st, gp);
                     p->cur ^= 1;
                     t_prev = h->obs_time[k];
                     continue;

@@ -1318,15 +1318,27 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
         bp[i] = run;
         run += bs[i];
     }
-    // ESS-adaptive mode: total of the squared weights and the decision (one thread; the tile count is small)
+    // ESS-adaptive mode: total of the squared weights (every thread its tiles, then wave and workgroup reduction; 128-bit
+    // integer sums are exact in any order) and the decision
+    __shared__ unsigned long long s_h2[kBlock / 64], s_l2[kBlock / 64];
+    if (a.ess_frac > 0.0) {
+        unsigned long long h2 = 0, l2 = 0;
+        const unsigned long long* b2 = a.blocksum2 + (int64_t)b * a.nblk * 2;
+        for (int i = lo; i < hi; ++i) add128(h2, l2, b2[2 * i], b2[2 * i + 1]);
+        wave_sum128(h2, l2);
+        if (lane == 0) {
+            s_h2[wid] = h2;
+            s_l2[wid] = l2;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == kBlock - 1) {
         const unsigned long long W = run;
         bool resample = true;
         if (a.ess_frac > 0.0) {
-            unsigned long long hi = 0, lo = 0;
-            const unsigned long long* b2 = a.blocksum2 + (int64_t)b * a.nblk * 2;
-            for (int i = 0; i < a.nblk; ++i) add128(hi, lo, b2[2 * i], b2[2 * i + 1]);
-            resample = ess_resample(W, hi, lo, a.ess_frac, a.P);
+            unsigned long long h2 = s_h2[0], l2 = s_l2[0];
+            for (int w = 1; w < kBlock / 64; ++w) add128(h2, l2, s_h2[w], s_l2[w]);
+            resample = ess_resample(W, h2, l2, a.ess_frac, a.P);
         }
         finish_segment(a, b, W, resample);
     }
@@ -1504,6 +1516,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
 // Slot i draws one uniform from its own stream (seed, segment, i, observation, DOMAIN_RESAMPLE_PARTICLE);
 // threshold t_i = i + u_i (stratified: one point per stratum) or P u_i (multinomial: i.i.d. points);
 // ancestor = first j with pos_j > t_i: tile through the tile_end_pos array in LDS, then 10 steps in L2.
+constexpr int kGatherPosStageTiles = 4096;  // tile_end_pos (8 B per tile) staged in LDS up to this many tiles
 struct GatherPosArgs {
     const int32_t* src;
     int32_t* dst;
@@ -1539,8 +1552,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_pos(GatherPosArgs a) {
         }
         return;
     }
-    for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_tep[t] = TE[t];
-    __syncthreads();
+    const bool staged = a.nblk <= kGatherPosStageTiles;  // (uniform) larger filters search the tile ends in L2
+    if (staged) {
+        for (int t = threadIdx.x; t < a.nblk; t += kBlock) s_tep[t] = TE[t];
+        __syncthreads();
+    }
     int j[kItems];
 #pragma unroll
     for (int q = 0; q < kItems; ++q) {
@@ -1549,7 +1565,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_pos(GatherPosArgs a) {
             Stream ps = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)i, a.obs_k, DOMAIN_RESAMPLE_PARTICLE);
             const double u = u01(stream_next(ps));
             const double thr = (a.rs_type == 2) ? (double)i + u : (double)a.P * u;
-            const int t = first_greater_d(s_tep, a.nblk, thr);
+            const int t = staged ? first_greater_d(s_tep, a.nblk, thr) : first_greater_d(TE, a.nblk, thr);
             const int within = first_greater_d(pos + (int64_t)t * kTile, kTile, thr);
             j[q] = min(t * kTile + within, a.P - 1);
         } else {

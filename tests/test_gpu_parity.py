@@ -640,3 +640,20 @@ def test_catalogue_models_at_chip_filling_size_all_schedules_agree(dp, orc, name
     assert ll1[0] == ref.ll and pf.last_event_count() == ref.events
     assert np.array_equal(pop.download(0), host)
     pf.close()
+
+
+@pytest.mark.parametrize("rs_type,ess,P", [(2, 0.0, 5 * (1 << 20)), (3, 0.0, 4 * (1 << 20) + 4097), (1, 0.5, 3 * (1 << 20)),
+                                           (2, 0.5, 3 * (1 << 20) + 5)])
+def test_many_tiles_other_resamplers_and_ess_sums(dp, orc, pooley, rs_type, ess, P):
+    """Filters of more than 4096 tiles (4 Mi particles: the stratified / multinomial gather searches the tile ends in
+    L2 instead of LDS) and of more than 2048 tiles in the ESS mode (separate scan kernel, parallel 128-bit sum of the
+    squared weights): the first observation -- propagation, weights, ESS decision, resampling -- against the oracle."""
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=rs_type, essc=ess, ess_adaptive=ess > 0)
+    theta = [0.003, 0.1]
+    pop = pf.alloc_population(1, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, 1, seed=77)
+    host = np.zeros((P, 2), dtype=np.int64)
+    ref = orc.pf_partial(pf.desc, host, theta, 1, 1, seed=77, rs_type=rs_type, nthreads=8, ess_frac=ess)
+    assert ll[0] == ref.ll and pf.last_event_count() == ref.events and pf.last_status[0] == ref.status
+    assert np.array_equal(pop.download(0), host)
+    pf.close()
