@@ -1,0 +1,36 @@
+"""Regression guard on speed: the headline workload (Pooley SIS, 2^20 particles, one full filter call) must stay within
+15 % of the committed profile (profiles/r02/bench.json, written by bench.py on the same kind of GPU), and the
+propagation kernel within 15 % of its committed average duration.  Collected near the end of the suite (warm GPU)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMITTED = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench.json")))
+TOLERANCE = 1.15
+
+
+def test_headline_workload_is_as_fast_as_the_committed_profile(dp, pooley):
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    P, theta = 1 << 20, [0.003, 0.1]
+    for i in range(40):                      # clocks of an idle GPU take ~20 calls to settle
+        pf.loglik(theta, P, seed=i)
+    times = []
+    for i in range(40):
+        t = time.perf_counter()
+        pf.loglik(theta, P, seed=100 + i)
+        times.append(time.perf_counter() - t)
+    ms = float(np.median(times)) * 1e3
+    pf.set_profiling(1)
+    for i in range(10):
+        pf.loglik(theta, P, seed=200 + i)
+    n, total_ms = pf.kernel_stats()["k_propagate"]
+    pf.close()
+    prop_us = total_ms / n * 1e3
+    assert ms <= TOLERANCE * COMMITTED["ms_per_step"], (ms, COMMITTED["ms_per_step"])
+    assert prop_us <= TOLERANCE * COMMITTED["kernels"]["k_propagate"]["avg_us"], (prop_us, COMMITTED["kernels"]["k_propagate"]["avg_us"])

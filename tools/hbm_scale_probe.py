@@ -28,20 +28,31 @@ def int64_bytes(P, S, B):
     return {"k_wsum": 8 * n, "k_offsets": 16 * n, "k_gather": (2 * S + 1) * 8 * n, "k_propagate": (2 * S + 1) * 8 * n}
 
 
-def run(name, model, y, theta, P, reps):
+def run(name, model, y, theta, P, reps, incremental=False):
+    """incremental: the filter as one call per observation on a device-resident population -- the way SMC^2 drives it
+    (src/hmm_ibis.jl:53-56); every call then ends on a resampling observation and runs the separate gather pass
+    (k_gather), which a whole-filter call folds into the next propagation."""
     pf = dp.ParticleFilter(model, y)
     B, S = theta.shape[1], model.n_states
+    pop = pf.alloc_population(B, P) if incremental else None
+
+    def one(seed):
+        if incremental:
+            for k in range(1, len(y) + 1):
+                pf.partial_log_likelihood(pop, theta, k, k, seed=seed)
+        else:
+            pf.loglik(theta, P, seed=seed)
     for i in range(2):
-        pf.loglik(theta, P, seed=i)
+        one(i)
     pf.set_profiling(1)
     for i in range(reps):
-        pf.loglik(theta, P, seed=10 + i)
+        one(10 + i)
     stats = pf.kernel_stats()
     pf.set_profiling(0)
     pf.close()
     mv, i64 = moved_bytes(P, S, B), int64_bytes(P, S, B)
     working_set = B * ((P + 1023) // 1024 * 1024) * (2 * 4 * S + 8 + 4)
-    out = {"filters": B, "particles_per_filter": P, "state_components": S, "working_set_MiB": round(working_set / 2 ** 20, 1),
+    out = {"incremental_calls": incremental, "filters": B, "particles_per_filter": P, "state_components": S, "working_set_MiB": round(working_set / 2 ** 20, 1),
            "fits_infinity_cache": working_set < 256 * 2 ** 20, "kernels": {}}
     for k, (n, ms) in stats.items():
         if not n or k not in mv:
@@ -70,5 +81,10 @@ if __name__ == "__main__":
         "sis_1x2^24": (sis, y_sis, np.tile(np.array([[0.003], [0.1]]), (1, 1)), 1 << 24),
         "seir_64x2^18": (seir, y_seir, th64, 1 << 18),
     }
-    res = {k: run(k, *v, reps) for k, v in configs.items() if not which or k in which}
+    res = {}
+    for k, v in configs.items():
+        if not which or k in which:
+            res[k] = run(k, *v, reps)
+        if k + "+incremental" in which or (not which and k in ("seir_64x2^16_config4_share", "seir_64x2^18")):
+            res[k + "+incremental"] = run(k, *v, reps, incremental=True)
     print(json.dumps(res, indent=1))
