@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdpomp_hip.so")
+LIB_PATH = os.environ.get("DPOMP_HIP_LIB") or os.path.join(HERE, "libdpomp_hip.so")  # (override: experiments, other installs)
 
 ABI_VERSION = 1
 MAX_STATES = 8
