@@ -83,10 +83,12 @@ DPOMP_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, 
 }
 
 // sfc64 step: additions, one shift-xor, one shift-add and one rotate -- on gfx950 the 64-bit adds and the
-// shift-add are single v_lshl_add_u64 instructions, ~11 VALU ops per 64 random bits (xoroshiro128++ needs ~19).
+// shift-add are single v_lshl_add_u64 instructions, 10 VALU ops per 64 random bits (xoroshiro128++ needs ~19).
 #if defined(__HIP_DEVICE_COMPILE__)
 // Device form of the same step.  c + (c << 3) is pinned to one v_lshl_add_u64 (the compiler otherwise rewrites it
-// as c * 9 and emits quarter-rate v_mad_u64_u32 pairs).
+// as c * 9 and emits quarter-rate v_mad_u64_u32 pairs).  The 64-bit rotate is two v_alignbit_b32 (the compiler's own
+// form is a 64-bit shift, a 32-bit shift and an or), and the add that follows is pinned to v_lshl_add_u64 as well:
+// left to the compiler, the halves of the rotate cost a register copy and a second add.  10 VALU instructions.
 __device__ __forceinline__ uint64_t stream_next(Stream& s) {
     const uint64_t t = s.a + s.b + s.n;
     s.n += 1;
@@ -94,8 +96,11 @@ __device__ __forceinline__ uint64_t stream_next(Stream& s) {
     uint64_t nb;
     asm("v_lshl_add_u64 %0, %1, 3, %1" : "=v"(nb) : "v"(s.c));
     s.b = nb;
-    s.c = ((s.c << 24) | (s.c >> 40)) + t;  // the compiler's own rotate (64-bit shift, 32-bit shift, or) + one add:
-                                            // assembling it from two v_alignbit halves costs a v_mov and a second add
+    const uint32_t lo = (uint32_t)s.c, hi = (uint32_t)(s.c >> 32);
+    const uint64_t rot = ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 8) << 32) | __builtin_amdgcn_alignbit(lo, hi, 8);  // rotl(c, 24)
+    uint64_t nc;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(nc) : "v"(rot), "v"(t));
+    s.c = nc;
     return t;
 }
 #else
