@@ -25,14 +25,13 @@ THETA = [0.003, 0.1]
 EXACT_LL = -15.6873794556  # exact CTMC forward algorithm (oracle/exact_sis.py)
 HBM_PEAK_GBS = 8000.0      # MI355X: 8.0 TB/s HBM3E spec
 HBM_MEASURED_COPY_GBS = 6290.0  # measured float4-copy rate of the chip (79 % of spec): the practical roof
-# VALU-issue ceiling of k_propagate: the SIS event loop is 69 VALU instructions per event (ISA of
-# k_propagate_c<RSir<2>,32>: 2 x 14 stream + uniform, 17 log, 10 division + range test, 6 rates, 5 event choice and
-# state update, 2 clock, 1 register copy).  Measured issue cost per wave64 instruction on gfx950
-# (tools/valu_rate_probe.hip -> profiles/r01_final/valu_issue_rates.json): FP64, 64-bit integer and three-operand
-# 32-bit ops 4 cycles, plain two-operand 32-bit ops (xor/add/or/and/shift: 16 of the 69) ~0.65 of that,
-# v_rcp_f64 3.4 x.  Hence 52 + 16 * 0.65 + 3.4 = 65.8 issue slots = 263 cycles per 64 events per SIMD; 1024 SIMDs
-# at 2.4 GHz.
-VALU_CYCLES_PER_WAVE_EVENT = (52 + 16 * 0.65 + 3.4) * 4
+# VALU-issue ceiling of k_propagate: the SIS event loop is 66 VALU instructions per event (ISA of
+# k_propagate_c<RSir<2>,32>: 2 x (10 stream step + 3 uniform), 17 log, 8 division + 2 range test, 6 rates, 5 event choice
+# and state update, 2 clock).  Measured issue cost per wave64 instruction on gfx950 (tools/valu_rate_probe.hip ->
+# profiles/r01_final/valu_issue_rates.json): FP64, 64-bit integer and three-operand 32-bit ops 4 cycles, plain
+# two-operand 32-bit ops (xor/add/or/and/shift: 12 of the 66) ~0.65 of that, v_rcp_f64 3.4 x.  Hence
+# 53 + 12 * 0.65 + 3.4 = 64.2 issue slots = 257 cycles per 64 events per SIMD; 1024 SIMDs at 2.4 GHz.
+VALU_CYCLES_PER_WAVE_EVENT = (53 + 12 * 0.65 + 3.4) * 4
 VALU_CEILING_EVENTS_PER_S = 1024 * 2.4e9 * 64 / VALU_CYCLES_PER_WAVE_EVENT
 
 
