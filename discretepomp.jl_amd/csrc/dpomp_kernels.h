@@ -813,6 +813,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     const int cap = a.m.cap;
     int cur = threadIdx.x;
+    const int n_start = min(kBlock, a.P - (int)blockIdx.x * kBlock);  // particles this workgroup starts with
+    // Events until the next count of live lanes (workgroup-uniform).  A count is a barrier for four waves, and it can
+    // only pay once particles have finished: CHK events at first, twice that while every particle of the workgroup still
+    // runs, 3/8 CHK once they have started to finish (the finer the packing, the fewer lanes idle in a live wave; below
+    // that the barriers cost more than the lanes they free), and no further count when one wave holds all that is left.
+    constexpr int kChunkMax = 2 * CHK, kChunkDie = 3 * CHK / 8, kChunkTail = 1 << 24;
+    int chunk = CHK;
     int ev_base = 0;      // wave-uniform: events every still-running particle of the workgroup has executed
     bool active = valid;  // particle still running
     bool parked = !valid; // final state already parked in s_res
@@ -824,7 +831,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             // every live lane of the workgroup has executed ev_base events so far (compaction moves contexts, not counts)
             capped = false;  // (this lane may hold another particle's context than last round)
-            const int lim = min(CHK, cap - ev_base);
+            const int lim = min(chunk, cap - ev_base);  // >= 1: a lane that reaches the cap stops being active
             int it = 0;
             bool go;
             do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
             }
             active = go;
         }
-        ev_base += CHK;
+        ev_base += min(chunk, cap - ev_base);  // (never past the cap: no overflow whatever the cap)
         if (!active && !parked) {  // once per particle, outside the hot loop
 #pragma unroll
             for (int s = 0; s < S; ++s) s_res[s][cur] = x[s];
@@ -851,6 +858,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
                   c3 = s_wcnt[round & 1][3];
         const int total = (c0 + c1) + (c2 + c3);
         if (total == 0) break;
+        chunk = total < n_start ? (total <= 64 ? kChunkTail : kChunkDie) : kChunkMax;
         const int waves_now = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
         if (((total + 63) >> 6) < waves_now) {  // workgroup-uniform
             const int rank = (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0) +
