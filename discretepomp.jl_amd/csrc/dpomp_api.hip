@@ -120,6 +120,11 @@ unsigned char* g_scratch_dev[kMaxDevices] = {};  // [device] device address of `
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 struct dpomp_handle {
+#ifdef DPOMP_TRACE_WG
+    unsigned long long* trace_buf = nullptr;
+    size_t trace_per = 0;
+    int trace_n = 0;
+#endif
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -682,6 +687,17 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         {
             const int rpl = pick_variant(k);
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
+#ifdef DPOMP_TRACE_WG
+            {
+                static unsigned long long* tr_buf = nullptr;
+                const size_t per = (size_t)((p->P + kBlock - 1) / kBlock) * B * 8;
+                if (!tr_buf) hipMalloc((void**)&tr_buf, per * 8 * 64);
+                a.trace = (k < 64) ? tr_buf + per * k : nullptr;
+                h->trace_buf = tr_buf;
+                h->trace_per = per;
+                h->trace_n = k + 1;
+            }
+#endif
             // iterate_particles! :56
             HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
             if (pending_gather) {
@@ -790,6 +806,18 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         t_prev = h->obs_time[k];  // :72
     }
     if (int rc = finish_call(h, p, st, p->ctl_result_bytes)) return rc;
+#ifdef DPOMP_TRACE_WG
+    if (const char* f = getenv("DPOMP_TRACE_WG_FILE")) {
+        std::vector<unsigned long long> host(h->trace_per * h->trace_n);
+        hipMemcpy(host.data(), h->trace_buf, host.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* fp = fopen(f, "wb")) {
+            const unsigned long long hdr[2] = {(unsigned long long)h->trace_n, (unsigned long long)h->trace_per};
+            fwrite(hdr, 8, 2, fp);
+            fwrite(host.data(), 8, host.size(), fp);
+            fclose(fp);
+        }
+    }
+#endif
     const char* const result_data = p->h_result;
     if (out_ll) memcpy(out_ll, result_data, (size_t)B * 8);
     memcpy(&h->last_events, result_data + (size_t)B * 8, 8);

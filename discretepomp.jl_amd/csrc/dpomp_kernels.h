@@ -79,6 +79,9 @@ struct PropArgs {
     const int32_t* offs;          // [B][Pp]    offspring boundaries N_j of that resampling
     const int32_t* first_parent;  // [B][Pp/256] parent block (of 256) of the first slot of every 256-slot block
     const int32_t* noresample;    // [B] or null: 1 = the population was kept (ESS-adaptive mode): slot p descends from p
+#ifdef DPOMP_TRACE_WG
+    unsigned long long* trace;    // [workgroups][8] timeline of every workgroup (experimental builds: tools/wg_timeline.py)
+#endif
 };
 
 constexpr int kParentBlock = 256;                       // granularity of the first_parent map (= slots per propagate workgroup)
@@ -783,6 +786,10 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     __shared__ unsigned long long s_ev[kBlock / 64];
     __shared__ int s_cap[kBlock / 64];
 
+#ifdef DPOMP_TRACE_WG
+    const unsigned long long tr_t0 = wall_clock64();
+    unsigned long long tr_t1 = 0, tr_x1 = 0, tr_x2 = 0, tr_x3 = 0;  // loop start; when the 2nd / 3rd / 4th wave emptied
+#endif
     const int b = blockIdx.y;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     const bool valid = p < a.P;
@@ -826,6 +833,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     bool capped = false;
     __syncthreads();
     Draws ahead = draw_ahead(rng, s_log, lr);  // (after the barrier: reads the log table in LDS)
+#ifdef DPOMP_TRACE_WG
+    tr_t1 = wall_clock64();
+#endif
 
     for (int round = 0;; ++round) {
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
@@ -861,6 +871,15 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
         chunk = total < n_start ? (total <= 64 ? kChunkTail : kChunkDie) : kChunkMax;
         const int waves_now = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
         if (((total + 63) >> 6) < waves_now) {  // workgroup-uniform
+#ifdef DPOMP_TRACE_WG
+            {
+                const unsigned long long now = wall_clock64();
+                const int need = (total + 63) >> 6;
+                if (need < 4 && !tr_x3) tr_x3 = now;
+                if (need < 3 && !tr_x2) tr_x2 = now;
+                if (need < 2 && !tr_x1) tr_x1 = now;
+            }
+#endif
             const int rank = (wid > 0 ? c0 : 0) + (wid > 1 ? c1 : 0) + (wid > 2 ? c2 : 0) +
                              __popcll(bal & ((1ull << lane) - 1ull));
             const bool take = (int)threadIdx.x < total;
@@ -961,6 +980,16 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
         if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
             sched_add(a.sched, be, 64ull * bs);
         }
+#ifdef DPOMP_TRACE_WG
+        if (a.trace) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* r = a.trace + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            r[0] = tr_t0; r[1] = tr_t1; r[2] = tr_x3; r[3] = tr_x2; r[4] = tr_x1; r[5] = wall_clock64();
+            r[6] = ((unsigned long long)xcc << 32) | hw; r[7] = be;
+        }
+#endif
     }
 }
 
