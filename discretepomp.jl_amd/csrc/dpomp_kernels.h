@@ -841,7 +841,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             // every live lane of the workgroup has executed ev_base events so far (compaction moves contexts, not counts)
             capped = false;  // (this lane may hold another particle's context than last round)
-            const int lim = min(chunk, cap - ev_base);  // >= 1: a lane that reaches the cap stops being active
+            // (>= 1: a lane that reaches the cap stops being active; read as a scalar so that the trip test stays off the VALU)
+            const int lim = __builtin_amdgcn_readfirstlane(min(chunk, cap - ev_base));
             int it = 0;
             bool go;
             do go = gillespie_event<R, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr);
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
         __syncthreads();
         const int c0 = s_wcnt[round & 1][0], c1 = s_wcnt[round & 1][1], c2 = s_wcnt[round & 1][2],
                   c3 = s_wcnt[round & 1][3];
-        const int total = (c0 + c1) + (c2 + c3);
+        const int total = __builtin_amdgcn_readfirstlane((c0 + c1) + (c2 + c3));  // (uniform: keeps the chunk length scalar)
         if (total == 0) break;
         chunk = total < n_start ? (total <= 64 ? kChunkTail : kChunkDie) : kChunkMax;
         const int waves_now = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
