@@ -48,10 +48,11 @@ def algorithmic_bytes(P, S):
 
 def moved_bytes(P, S):
     """Bytes per launch the kernels really have to move: the state lives in HBM as int32, the offspring boundaries as
-    int32, log-weights as f64.  (The resampling gather of a full filter call runs inside the next k_propagate.)"""
+    int32, log-weights as f64, fixed-point weights as u64 (written by k_wsum, read by k_offsets).  (The resampling
+    gather of a full filter call runs inside the next k_propagate.)"""
     return {
         "k_propagate": (4 * S + 4 * S + 8) * P,
-        "k_wsum": 8 * P,
+        "k_wsum": (8 + 8) * P,
         "k_scan_blocks": 0,
         "k_offsets": (8 + 4) * P,
         "k_gather": (4 + 4 * S + 4 * S) * P,

@@ -179,6 +179,7 @@ struct dpomp_pop {
     int cur = 0;
     double* logw = nullptr;
     int32_t* offs = nullptr;
+    unsigned long long* wfix = nullptr;    // [B][Pp] fixed-point weights of the current observation
     unsigned long long* blocksum = nullptr;
     unsigned long long* blockprefix = nullptr;
     int32_t* tile_end = nullptr;           // [B][Pp/256] first_parent map of the last systematic resampling
@@ -352,6 +353,7 @@ void pop_release(dpomp_pop* p) {
     for (int i = 0; i < 2; ++i) (void)hipFree(p->state[i]);
     (void)hipFree(p->logw);
     (void)hipFree(p->offs);
+    (void)hipFree(p->wfix);
     (void)hipFree(p->blocksum);
     (void)hipFree(p->blockprefix);
     (void)hipFree(p->tile_end);
@@ -423,6 +425,7 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->state[1], n_state * sizeof(int32_t));
     DPOMP_ALLOC(p->logw, (size_t)B * p->Pp * sizeof(double));
     DPOMP_ALLOC(p->offs, (size_t)B * p->Pp * sizeof(int32_t));
+    DPOMP_ALLOC(p->wfix, (size_t)B * p->Pp * 8);
     DPOMP_ALLOC(p->blocksum, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->blockprefix, (size_t)B * p->nblk * 8);
     DPOMP_ALLOC(p->tile_end, (size_t)B * (p->Pp / kParentBlock) * 4);
@@ -462,6 +465,7 @@ size_t pop_carve(dpomp_handle* h, dpomp_pop* p, unsigned char* base) {
     p->state[1] = reinterpret_cast<int32_t*>(take(n_state * 4));
     p->logw = reinterpret_cast<double*>(take(B * p->Pp * 8));
     p->offs = reinterpret_cast<int32_t*>(take(B * p->Pp * 4));
+    p->wfix = reinterpret_cast<unsigned long long*>(take(B * p->Pp * 8));
     p->blocksum = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
     p->blockprefix = reinterpret_cast<unsigned long long*>(take(B * p->nblk * 8));
     p->tile_end = reinterpret_cast<int32_t*>(take(B * (p->Pp / kParentBlock) * 4));
@@ -719,6 +723,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.ll = p->ll;
             w.status = p->status;
             w.offs = p->offs;
+            w.wfix = p->wfix;
             w.tile_end = p->tile_end;
             w.posw = p->posw;
             w.tile_end_pos = p->tile_end_pos;

@@ -1223,6 +1223,7 @@ __global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
 // ---- weights -----------------------------------------------------------------------------------
 struct WeightArgs {
     const double* logw;                 // [B][Pp]
+    unsigned long long* wfix;           // [B][Pp] fixed-point weights: written by k_wsum, read by k_offsets
     const unsigned long long* segmax;   // [B]
     unsigned long long* blocksum;       // [B][nblk]
     unsigned long long* blockprefix;    // [B][nblk] exclusive prefix of blocksum
@@ -1260,6 +1261,19 @@ __device__ __forceinline__ void load_tile_weights(const WeightArgs& a, int b, in
     const double g[kItems] = {g01.x, g01.y, g23.x, g23.y};
 #pragma unroll
     for (int q = 0; q < kItems; ++q) w[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
+    // kept for k_offsets: the exponential is evaluated once per particle and observation
+    ulonglong2* dst = reinterpret_cast<ulonglong2*>(a.wfix + (int64_t)b * a.Pp + i0);
+    dst[0] = make_ulonglong2(w[0], w[1]);
+    dst[1] = make_ulonglong2(w[2], w[3]);
+}
+__device__ __forceinline__ void load_tile_fixed(const WeightArgs& a, int b, int blk, unsigned long long (&w)[kItems]) {
+    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(a.wfix + (int64_t)b * a.Pp + i0);
+    const ulonglong2 w01 = src[0], w23 = src[1];
+    w[0] = w01.x;
+    w[1] = w01.y;
+    w[2] = w23.x;
+    w[3] = w23.y;
 }
 
 __device__ __forceinline__ void add128(unsigned long long& hi, unsigned long long& lo, unsigned long long h,
@@ -1420,7 +1434,7 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         return;  // k_scan_blocks decided to keep this segment's population
     }
     unsigned long long w[kItems];
-    load_tile_weights(a, b, blk, w);
+    load_tile_fixed(a, b, blk, w);
     unsigned long long c[kItems];
     c[0] = w[0];
 #pragma unroll
@@ -1474,7 +1488,7 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         double ps[kItems];
 #pragma unroll
         for (int q = 0; q < kItems; ++q)
-            ps[q] = (W == 0) ? (double)a.P : (u64_to_double(base + c[q]) / Wd) * (double)a.P;
+            ps[q] = (W == 0) ? (double)a.P : div_in_range(u64_to_double(base + c[q]), Wd) * (double)a.P;
         double* dst = a.posw + (int64_t)b * a.Pp + i0;
         *reinterpret_cast<double2*>(dst) = make_double2(ps[0], ps[1]);
         *reinterpret_cast<double2*>(dst + 2) = make_double2(ps[2], ps[3]);

@@ -216,9 +216,11 @@ DPOMP_D double dlog(double x) { return dlog_tab(x, kLogTable); }
 // The compiler expands a / b into v_div_scale x2, v_rcp_f64, two Newton steps, q0 = a y, r = a - b q0,
 // v_div_fmas (q0 + r y) and v_div_fixup; the scale / fmas / fixup instructions only act when an operand or the
 // quotient is zero, subnormal, infinite, NaN or needs pre-scaling against overflow.  For 2^-200 <= b <= 2^200 and
-// 2^-60 <= |a| <= 2^60 they are identities, and the remaining eight instructions are the same Newton-Markstein
-// sequence, so the result is the correctly rounded quotient -- what `/` gives on the host (checked against `/` by
-// dpomp_selftest_numerics and, implicitly, by every parity test).  |log(u)| is in [2^-53, 37] by construction;
+// a = 0 or 2^-200 <= |a| <= 2^200 they are identities (a = 0 gives 0 either way), and the remaining eight instructions
+// are the same Newton-Markstein sequence, so the result is the correctly rounded quotient -- what `/` gives on the
+// host (checked against `/` by dpomp_selftest_numerics and, implicitly, by every parity test).  The other users --
+// the quotient inside dexp and the scaled cumulative weight c / W -- are in that range by construction.
+// |log(u)| is in [2^-53, 37] by construction;
 // the rate total is tested (one integer compare on its high word) and anything else -- a zero total, i.e. a
 // particle that can no longer move, included -- leaves the fast event loop for one with the plain division.
 __device__ __forceinline__ bool rate_in_fast_range(double total) {
@@ -254,7 +256,8 @@ DPOMP_HD double dexp(double x) {
     const double r = hi - lo;
     const double tt = r * r;
     const double c = r - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
-    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    // (|r c| is 0 or in [2^-140, 0.2] and 2 - c in [1.6, 2.4]: the short division gives the IEEE quotient)
+    const double y = 1.0 - ((lo - div_in_range(r * c, 2.0 - c)) - hi);
     return bits_to_double(double_to_bits(y) + ((uint64_t)(int64_t)k << 52));
 }
 
@@ -282,7 +285,7 @@ DPOMP_HD uint64_t fixed_weight(double g, double m, int sh) {
 DPOMP_HD int64_t offspring_end(uint64_t c, uint64_t W, int64_t P, double r) {
     if (c >= W) return P;
     const double Wd = u64_to_double(W);
-    const double pos = (u64_to_double(c) / Wd) * (double)P - r;
+    const double pos = div_in_range(u64_to_double(c), Wd) * (double)P - r;  // (0 <= c < W, 1 <= W < 2^63: in range)
     const double n = __builtin_ceil(pos);
     if (!(n > 0.0)) return 0;
     if (n > (double)P) return P;

@@ -213,7 +213,7 @@ int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, 
  * handle is set to), but every working buffer of the call lives in one static device array of
  * DPOMP_STATIC_MAX_BYTES that each GPU the library runs on holds until the process ends; the call performs no
  * hipMalloc / hipFree / hipHostMalloc / event creation (per-kernel profiling is off for it).  Calls whose working set
- * (about (8 S + 12) bytes per particle, plus 20 with resamplers 2/3) exceeds the array, or with
+ * (about (8 S + 20) bytes per particle, plus 8 with resamplers 2/3) exceeds the array, or with
  * B > DPOMP_STATIC_MAX_SEGMENTS, are rejected with DPOMP_EINVAL.  All calls on one GPU share that GPU's array, from
  * every handle and thread: calls that overlap on one GPU race -- serialise them. */
 #define DPOMP_STATIC_MAX_BYTES (16u << 20)

@@ -83,13 +83,13 @@ def test_static_entry_point_rejects_what_does_not_fit(dp, pooley):
     def call(B, P, theta=th):
         return lib.dpomp_pf_loglik_static(pf._h, theta.ctypes.data_as(C.POINTER(C.c_double)), B, P, 1, 0,
                                           ll.ctypes.data_as(C.POINTER(C.c_double)), None)
-    assert call(1, 1 << 20) == dp._abi.EINVAL      # 28 B per particle x 2^20 > 16 MiB
+    assert call(1, 1 << 20) == dp._abi.EINVAL      # 36 B per particle x 2^20 > 16 MiB
     msg = lib.dpomp_last_error(pf._h).decode()
     assert "static scratch" in msg and "dpomp_pf_loglik" in msg, msg
     big = np.ascontiguousarray(np.tile(th, (dp._abi.STATIC_MAX_SEGMENTS + 1, 1)))
     ll = np.zeros(dp._abi.STATIC_MAX_SEGMENTS + 1)
     assert call(dp._abi.STATIC_MAX_SEGMENTS + 1, 8, big) == dp._abi.EINVAL
     assert "maximum" in lib.dpomp_last_error(pf._h).decode()
-    # the largest SIS call that fits (28 B per particle + control block) still runs and agrees
-    _same(*_pair(pf, [0.003, 0.1], 590000, seed=2))
+    # the largest SIS call that fits (36 B per particle + control block) still runs and agrees
+    _same(*_pair(pf, [0.003, 0.1], 460000, seed=2))
     pf.close()

@@ -17,9 +17,10 @@ HBM_PEAK, HBM_MEASURED_COPY = 8000.0, 6290.0   # GB/s: spec, and the measured fl
 
 def moved_bytes(P, S, B):
     """HBM bytes each kernel has to move per launch with int32 state (what is in memory), per DESIGN.md's layout:
-    k_wsum reads logw; k_offsets reads logw, writes N_j (int32); k_gather reads N_j, gathers and writes the state."""
+    k_wsum reads logw and writes the fixed-point weights; k_offsets reads those and writes N_j (int32); k_gather reads
+    N_j, gathers and writes the state."""
     n = P * B
-    return {"k_wsum": 8 * n, "k_offsets": (8 + 4) * n, "k_gather": (4 + 4 * S + 4 * S) * n,
+    return {"k_wsum": (8 + 8) * n, "k_offsets": (8 + 4) * n, "k_gather": (4 + 4 * S + 4 * S) * n,
             "k_propagate": (4 * S + 4 * S + 8) * n}
 
 
@@ -51,7 +52,7 @@ def run(name, model, y, theta, P, reps, incremental=False):
     pf.set_profiling(0)
     pf.close()
     mv, i64 = moved_bytes(P, S, B), int64_bytes(P, S, B)
-    working_set = B * ((P + 1023) // 1024 * 1024) * (2 * 4 * S + 8 + 4)
+    working_set = B * ((P + 1023) // 1024 * 1024) * (2 * 4 * S + 8 + 8 + 4)
     out = {"incremental_calls": incremental, "filters": B, "particles_per_filter": P, "state_components": S, "working_set_MiB": round(working_set / 2 ** 20, 1),
            "fits_infinity_cache": working_set < 256 * 2 ** 20, "kernels": {}}
     for k, (n, ms) in stats.items():
