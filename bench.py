@@ -64,12 +64,13 @@ def pmc_traffic(kernel):
     WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no profile is present."""
     best = None
     root = os.path.join(ROOT, "profiles")
-    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:
-        f = os.path.join(root, d, "pmc_hbm_traffic.json")
-        if os.path.exists(f):
-            for name, v in json.load(open(f)).items():
-                if name.split("::")[-1].split("<")[0] == kernel:
-                    best = (v.get("hbm_bytes_per_launch_corrected"), d)
+    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:  # (the latest round's bench passes win)
+        for sub in ("", "bench"):
+            f = os.path.join(root, d, sub, "pmc_hbm_traffic.json")
+            if os.path.exists(f):
+                for name, v in json.load(open(f)).items():
+                    if name.split("::")[-1].split("<")[0] == kernel:
+                        best = (v.get("hbm_bytes_per_launch_corrected"), os.path.join(d, sub).rstrip("/"))
     return best
 
 

@@ -8,7 +8,7 @@ set -e -o pipefail
 OUT=${1:-gpurun_out/prof2}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
-mkdir -p "$OUT"
+mkdir -p "$OUT/hbm"
 [ -n "$SKIP_BENCH" ] || bash tools/collect_profiles.sh "$OUT/bench"
 P="python3 tools/hbm_scale_probe.py 4 sis_16x2^20 seir_64x2^18 seir_64x2^18+incremental seir_64x2^16_config4_share seir_64x2^16_config4_share+incremental"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hbm/trace" -- $P > "$OUT/hbm/probe_under_rocprof.json" 2> "$OUT/hbm/trace.err"

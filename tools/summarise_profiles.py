@@ -5,6 +5,7 @@
     pmc_hbm_traffic.json    FETCH_SIZE / WRITE_SIZE per launch and kernel; hbm_bytes_per_launch_corrected doubles the
                             FETCH_SIZE figure as MI355X_MICROARCH.md prescribes for gfx950 (counter units: KiB)
     pmc_sq_counters.json    SQ counters per launch and kernel, with derived VALU busy fraction, lane utilisation, clock
+    by_launch_shape.json    duration and HBM bytes per kernel and launch shape (number of workgroups)
 
     python tools/summarise_profiles.py <raw dir> <out dir>
 """
@@ -56,6 +57,39 @@ def durations(raw, sub):
     return acc
 
 
+def by_grid(raw):
+    """Per kernel AND launch shape (a probe that runs several configurations launches the same kernel with different
+    grids): average duration from the trace pass, FETCH_SIZE / WRITE_SIZE from the counter passes."""
+    acc = defaultdict(lambda: {"us": [], "fetch": [], "write": []})
+
+    def key(r):  # (kernel, workgroups of the launch)
+        if "Grid_Size_X" in r:
+            threads = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+        else:
+            threads, wg = int(r["Grid_Size"]), int(r["Workgroup_Size"])
+        return short(r["Kernel_Name"]), f"{threads // wg} workgroups"
+    f = newest(os.path.join(raw, "trace", "**", "*kernel_trace.csv"))
+    if f:
+        for r in csv.DictReader(open(f)):
+            if "dpomp" in r["Kernel_Name"]:
+                acc[key(r)]["us"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for sub, field in (("pmc_fetch", "fetch"), ("pmc_write", "write")):
+        f = newest(os.path.join(raw, sub, "**", "*counter_collection.csv"))
+        if f:
+            for r in csv.DictReader(open(f)):
+                if "dpomp" in r["Kernel_Name"]:
+                    acc[key(r)][field].append(float(r["Counter_Value"]))
+    out = {}
+    for (k, g), v in sorted(acc.items()):
+        if not v["us"]:
+            continue
+        avg = lambda x: sum(x) / len(x) if x else 0.0
+        out.setdefault(k, {})[g] = {"launches": len(v["us"]), "avg_us": round(avg(v["us"]), 2), "min_us": round(min(v["us"]), 2),
+                                    "hbm_bytes_per_launch_corrected": round((2.0 * avg(v["fetch"]) + avg(v["write"])) * 1024.0)}
+    return out
+
+
 def main(raw, out):
     os.makedirs(out, exist_ok=True)
     stats = newest(os.path.join(raw, "trace", "**", "*kernel_stats.csv"))
@@ -73,6 +107,7 @@ def main(raw, out):
         hbm[k] = {"FETCH_SIZE_KB_avg": fa, "launches_FETCH_SIZE": len(f), "WRITE_SIZE_KB_avg": wa,
                   "launches_WRITE_SIZE": len(w), "hbm_bytes_per_launch_corrected": (2.0 * fa + wa) * 1024.0}
     json.dump(hbm, open(os.path.join(out, "pmc_hbm_traffic.json"), "w"), indent=1)
+    json.dump(by_grid(raw), open(os.path.join(out, "by_launch_shape.json"), "w"), indent=1)
 
     sq = defaultdict(dict)
     for sub in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
