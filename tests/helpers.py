@@ -35,6 +35,22 @@ class OraclePop:
         pass
 
 
+_POOL = None
+
+
+def threaded(fn, n):
+    """[fn(0), ..., fn(n-1)] on a few threads: independent oracle filters (ctypes releases the GIL, one filter is one
+    serial C call), so the CPU suite uses the cores it has."""
+    global _POOL
+    if n < 2:
+        return [fn(i) for i in range(n)]
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)))))
+    return list(_POOL.map(fn, range(n)))
+
+
 class OracleBank:
     def __init__(self, dp, orc, model, obs):
         self.orc, self.desc = orc, dp.ModelDescriptor(model, obs)
@@ -45,8 +61,8 @@ class OracleBank:
 
     def partial_log_likelihood(self, pop, theta, ymin, ymax, seed=1, seg_base=0):
         theta = np.asarray(theta)
-        return np.array([self.orc.pf_partial(self.desc, pop.pops[b], theta[:, b], ymin, ymax, seed=seed, seg=seg_base + b).ll
-                         for b in range(pop.B)])
+        return np.array(threaded(lambda b: self.orc.pf_partial(self.desc, pop.pops[b], theta[:, b], ymin, ymax, seed=seed,
+                                                               seg=seg_base + b).ll, pop.B))
 
 
 # every catalogue model of generate_model (src/hmm_examples.jl:171-204), density and frequency dependent:

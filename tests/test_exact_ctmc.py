@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from helpers import CATALOGUE_CASES, synthetic_data
+from helpers import CATALOGUE_CASES, synthetic_data, threaded
 from oracle import exact_ctmc, exact_sis
 
 EXACT = json.load(open(os.path.join(GOLDEN, "exact_ctmc.json")))
@@ -49,7 +49,7 @@ def test_oracle_is_unbiased_against_the_exact_seir_likelihood(dp, orc, mode, whi
     g = EXACT["SEIR"][which]
     m = orc.MODE_SPEC if mode == "spec" else orc.MODE_FAITHFUL
     R = 128
-    lls = np.array([orc.pf_loglik(desc, 1024, g["theta"], seed=s, mode=m).ll for s in range(1, R + 1)])
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 1024, g["theta"], seed=s + 1, mode=m).ll, R))
     ratio = np.exp(lls - g["ll"])
     se = ratio.std(ddof=1) / math.sqrt(R)
     assert abs(ratio.mean() - 1.0) < 3.5 * se and se < 0.02, (ratio.mean(), se)
@@ -61,7 +61,7 @@ def test_oracle_is_unbiased_against_the_exact_lotka_likelihood(dp, orc):
     desc = dp.ModelDescriptor(dp.generate_model("LOTKA", LOTKA_X0), y)
     g = EXACT["LOTKA"][1]
     R = 48
-    lls = np.array([orc.pf_loglik(desc, 2048, g["theta"], seed=s, nthreads=4).ll for s in range(1, R + 1)])
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 2048, g["theta"], seed=s + 1).ll, R))
     ratio = np.exp(lls - g["ll"])
     se = ratio.std(ddof=1) / math.sqrt(R)
     assert abs(ratio.mean() - 1.0) < 3.5 * se, (ratio.mean(), se)

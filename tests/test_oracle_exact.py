@@ -5,6 +5,7 @@ import math
 import numpy as np
 import pytest
 
+from helpers import threaded
 from oracle import exact_sis
 
 KNOWN = {  # SURVEY.md 8(c), re-derived by oracle/exact_sis.py
@@ -58,7 +59,7 @@ def test_pf_is_unbiased_on_the_likelihood_scale(dp, orc, pooley, mode):
     theta = (0.003, 0.1)
     R = 160
     m = orc.MODE_SPEC if mode == "spec" else orc.MODE_FAITHFUL
-    lls = np.array([orc.pf_loglik(desc, 1024, theta, seed=s, mode=m).ll for s in range(1, R + 1)])
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 1024, theta, seed=s + 1, mode=m).ll, R))
     exact = KNOWN[theta]
     ratio = np.exp(lls - exact)
     se = ratio.std(ddof=1) / math.sqrt(R)
@@ -70,7 +71,7 @@ def test_pf_is_unbiased_on_the_likelihood_scale(dp, orc, pooley, mode):
 def test_other_thetas_statistically(dp, orc, pooley):
     desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), pooley)
     for theta, exact in KNOWN.items():
-        lls = np.array([orc.pf_loglik(desc, 2048, theta, seed=100 + s).ll for s in range(48)])
+        lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 2048, theta, seed=100 + s).ll, 48))
         ratio = np.exp(lls - exact)
         assert abs(ratio.mean() - 1.0) < 4 * ratio.std(ddof=1) / math.sqrt(len(lls))
 
@@ -108,7 +109,7 @@ def test_stratified_and_multinomial_resamplers(dp, orc, pooley, rs_type):
         assert abs(a.ll - b.ll) < 1e-11 and int((a.ancestors != b.ancestors).sum()) <= 1
         if rs_type == 2:
             assert np.all(np.diff(a.ancestors) >= 0)  # one point per stratum: ancestors stay sorted
-    lls = np.array([orc.pf_loglik(desc, 1024, theta, seed=200 + s, rs_type=rs_type).ll for s in range(120)])
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 1024, theta, seed=200 + s, rs_type=rs_type).ll, 120))
     ratio = np.exp(lls - KNOWN[theta])
     assert abs(ratio.mean() - 1.0) < 3.5 * ratio.std(ddof=1) / math.sqrt(len(lls))
 
@@ -124,7 +125,7 @@ def test_ess_adaptive_resampling_in_the_oracle(dp, orc, pooley):
         assert a.ll == b.ll and np.array_equal(a.pop, b.pop)
     differs = sum(orc.pf_loglik(desc, 1024, theta, seed=s, ess_frac=0.3).ll != orc.pf_loglik(desc, 1024, theta, seed=s).ll for s in range(1, 11))
     assert differs >= 5
-    lls = np.array([orc.pf_loglik(desc, 1024, theta, seed=300 + s, ess_frac=0.3).ll for s in range(140)])
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 1024, theta, seed=300 + s, ess_frac=0.3).ll, 140))
     ratio = np.exp(lls - KNOWN[theta])
     assert abs(ratio.mean() - 1.0) < 3.5 * ratio.std(ddof=1) / math.sqrt(len(lls))
     # incremental calls carry the state exactly like one call

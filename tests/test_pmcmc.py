@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import threaded
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EXACT = json.load(open(os.path.join(GOLDEN, "pf_golden.json")))["exact_pooley_sis_evidence_u001_u05"]
 
@@ -35,7 +37,7 @@ def test_pmmh_with_the_oracle_filter(dp, orc, pooley):
     prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
 
     def evaluate(th, seed):
-        return np.array([orc.pf_loglik(desc, 64, th[:, c], seed=seed, seg=c).ll for c in range(th.shape[1])])
+        return np.array(threaded(lambda c: orc.pf_loglik(desc, 64, th[:, c], seed=seed, seg=c).ll, th.shape[1]))
 
     # the scale moves by x1.002 / x0.999 per step from c0 = 0.1 (reference constants), so adaptation needs
     # a few thousand steps; the reference's defaults are 50000 steps with 10000 of adaptation
