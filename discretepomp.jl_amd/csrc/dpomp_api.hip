@@ -36,7 +36,8 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 
 typedef void (*PropFn)(PropArgs);
 
-constexpr int64_t kCompactionMinWaves = 8192;
+constexpr int64_t kCompactionMinWaves = 4096;   // launches of at least this many waves run the compaction schedule
+constexpr int64_t kSmallFilterMaxWaves = 8192;  // calls of P <= 256 below this many waves run the whole-filter kernel
 constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
 // Automatic schedule, per observation interval.  A launch that fills the chip (>= 8192 waves: the issue slots a
 // compaction frees are taken by other waves) runs with workgroup compaction unless, the last time this handle ran the
@@ -45,6 +46,7 @@ constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (DESIGN.m
 // utilisations of 0.75-0.87 and by 20-30 % where epidemics die out early (0.3); below 8192 waves the static kernel
 // wins by 2-7 %.
 constexpr double kCompactionBelowUtil = 0.90;
+constexpr double kBoostChainFrac = 0.72;  // head start of the last workgroups: share of a wave's event chain (tools/ab_probe.py)
 constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
@@ -164,6 +166,9 @@ struct dpomp_handle {
     std::vector<PendingTiming> pending;
     uint64_t last_events = 0;
     std::vector<double> lane_util;  // [T] lane utilisation a one-particle-per-lane schedule had / would have had, last call (-1 = unknown)
+    std::vector<double> wave_chain; // [T] mean over waves of the longest event chain in the wave, last call (-1 = unknown)
+    int resident_wgs = 2048;        // workgroups of the compaction kernel the device holds at once (8 per CU)
+    bool no_head_start = false;     // DPOMP_HEAD_START=0: experiment switch
     std::string err;
     // scratch for dpomp_pf_loglik
     dpomp_pop* scratch_pop = nullptr;
@@ -594,7 +599,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     // (Thousands of such filters in one call fill the chip with the multi-kernel path, whose workgroup compaction then
     // beats the whole-filter kernel's static lanes: 4000 x 200 particles 2.83 against 2.90 ms.)
     if (p->P <= kBlock && h->small_filter && h->force_rpl == 0 && h->rs_type == DPOMP_RS_SYSTEMATIC && !adaptive &&
-        domain == DOMAIN_PROPAGATE && !record_states && B * ((p->P + 63) / 64) < kCompactionMinWaves) {
+        domain == DOMAIN_PROPAGATE && !record_states && B * ((p->P + 63) / 64) < kSmallFilterMaxWaves) {
         SmallArgs sa;
         sa.m = h->dm;
         sa.state = p->state[p->cur];
@@ -638,10 +643,11 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     if (ymin == 1) p->initialised = true;  // pop[i,:] .= initial_condition (:41-45) happens inside the first propagation
     double t_prev = (ymin == 1) ? 0.0 : h->obs_time[ymin - 2];  // :45-47
 
-    // Schedule of the propagation towards observation k (0-based): enough waves must remain to fill 256 CUs x 4 SIMDs
-    // several times over.  Default: workgroup compaction once the launch saturates the chip (>= 8192 waves: freed issue
-    // slots are taken by other waves) unless the interval kept the lanes busy last time; below that the plain kernel
-    // wins by 10-15 % (tools/latency_probe.py).  lane_util = -1 (not measured yet) -> compaction.
+    // Schedule of the propagation towards observation k (0-based).  Default: workgroup compaction once the launch holds
+    // at least half of what the chip keeps resident (>= 4096 waves: with the head start of the last workgroups it beats
+    // the plain kernel by 5-9 % from 2^18 particles on, tools/size_probe.py) unless the interval kept the lanes busy last
+    // time; below that the plain kernel wins (the issue slots a compaction frees have no other wave to go to).
+    // lane_util = -1 (not measured yet) -> compaction.
     auto pick_variant = [&](int k) {
         if (h->force_rpl) return h->force_rpl;
         return (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
@@ -691,6 +697,15 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         {
             const int rpl = pick_variant(k);
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
+            // Head start of the compaction kernel: the last half round of workgroups, for kBoostChainFrac of the event
+            // chain a wave had in this interval at the previous call (none before anything has been measured).
+            a.boost_events = 0;
+            a.boost_from = 0;
+            if ((rpl == 16 || rpl == 32) && h->wave_chain[k] > 0.0 && !h->no_head_start) {
+                const int64_t n_wg = (p->P + kBlock - 1) / kBlock * B;
+                a.boost_from = (int32_t)std::max<int64_t>(0, n_wg - h->resident_wgs / 2);
+                a.boost_events = (int32_t)std::min(1.0e9, std::max(1.0, kBoostChainFrac * h->wave_chain[k]));
+            }
 #ifdef DPOMP_TRACE_WG
             {
                 static unsigned long long* tr_buf = nullptr;
@@ -836,7 +851,10 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
                 slots += sc[kSchedStride * k + (kSchedSlots + s2) * kSchedLine];
             }
             h->last_events += ev;  // the propagate kernels count events per interval
-            if (slots && domain == DOMAIN_PROPAGATE) h->lane_util[k] = (double)ev / (double)slots;
+            if (slots && domain == DOMAIN_PROPAGATE) {
+                h->lane_util[k] = (double)ev / (double)slots;
+                h->wave_chain[k] = (double)slots / (64.0 * (double)(B * ((p->P + 63) / 64)));
+            }
         }
     }
     return DPOMP_OK;
@@ -1195,6 +1213,13 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         return rc;
     }
     h->stream = h->own_stream;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            h->resident_wgs = cus * 8;  // 8 waves per SIMD, 4 SIMDs per CU, 4 waves per workgroup
+        const char* hs = getenv("DPOMP_HEAD_START");
+        h->no_head_start = hs && hs[0] == '0';
+    }
     {   // device address of the static scratch array on THIS GPU (each device holds its own copy), once per device
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
         if (device < kMaxDevices && !g_scratch_dev[device]) {
@@ -1220,6 +1245,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     }
     h->T = d->n_obs;
     h->lane_util.assign((size_t)d->n_obs, -1.0);
+    h->wave_chain.assign((size_t)d->n_obs, -1.0);
     h->obs_time.assign(d->obs_time, d->obs_time + d->n_obs);
     h->obs_id.assign(d->obs_id, d->obs_id + d->n_obs);
     h->ysum.resize(d->n_obs);

@@ -79,6 +79,10 @@ struct PropArgs {
     const int32_t* offs;          // [B][Pp]    offspring boundaries N_j of that resampling
     const int32_t* first_parent;  // [B][Pp/256] parent block (of 256) of the first slot of every 256-slot block
     const int32_t* noresample;    // [B] or null: 1 = the population was kept (ESS-adaptive mode): slot p descends from p
+    // Head start (compaction kernel): the workgroups of the launch from linear index `boost_from` on -- those that are
+    // dispatched last -- run at raised wave priority until their particles have executed `boost_events` events
+    // (0 = no head start).  Scheduling only: results do not depend on it.
+    int32_t boost_from, boost_events;
 #ifdef DPOMP_TRACE_WG
     unsigned long long* trace;    // [workgroups][8] timeline of every workgroup (experimental builds: tools/wg_timeline.py)
 #endif
@@ -837,7 +841,18 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     tr_t1 = wall_clock64();
 #endif
 
+    // Head start for the workgroups that are dispatched last.  The hardware serves the oldest waves of a SIMD first, so
+    // without it a launch ends with every CU working off its youngest workgroups, which have most of their event
+    // chains left, at one or two live waves per SIMD (a lone wave is bound by instruction latency, not issue).  At
+    // raised priority for the first ~70 % of its chain, the youngest half of the last round catches up with the older
+    // half and the workgroups of a CU finish together.
+    bool boosted = a.boost_events > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) >= a.boost_from;
+    if (boosted) __builtin_amdgcn_s_setprio(3);
     for (int round = 0;; ++round) {
+        if (boosted && ev_base >= a.boost_events) {  // (wave-uniform)
+            boosted = false;
+            __builtin_amdgcn_s_setprio(0);
+        }
         if (active) {  // up to CHK events per live lane: the static kernel's divergent loop plus a uniform trip counter
             // every live lane of the workgroup has executed ev_base events so far (compaction moves contexts, not counts)
             capped = false;  // (this lane may hold another particle's context than last round)

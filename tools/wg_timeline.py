@@ -47,5 +47,22 @@ for k in range(n):
     per_cu = np.array([(cu == c).sum() for c in np.unique(cu)])
     print(f"   {len(ends)} CUs: workgroups per CU {per_cu.min()}..{per_cu.max()}, CU finishes at {ends.mean():6.1f} +- {ends.std():4.1f} us"
           f" (first {ends.min():.1f}, last {ends.max():.1f}): idle CU time before the launch ends {100 * (1 - ends.mean() / span):.1f} %")
+    # time-weighted histogram, over all CUs, of the number of live waves on a CU (32 wave slots, 4 SIMDs)
+    hist = np.zeros(34)
+    for c in np.unique(cu):
+        m = cu == c
+        ev = [(t, +1) for t in t1[m]] * 1
+        ev = []
+        for s_, e_ in ((t1[m], x3[m]), (t1[m], x2[m]), (t1[m], x1[m]), (t1[m], t5[m])):
+            ev += [(int(t), 1) for t in s_] + [(int(t), -1) for t in e_]
+        ev.sort()
+        cur, last = 0, int(base)
+        for t, d in ev:
+            hist[min(cur, 33)] += t - last
+            cur, last = cur + d, t
+        hist[0] += int(t5.max()) - last
+    hist /= hist.sum()
+    print("   share of CU time with n live waves on the CU: 0: %.3f  1-4: %.3f  5-8: %.3f  9-12: %.3f  13-16: %.3f  17+: %.3f"
+          % (hist[0], hist[1:5].sum(), hist[5:9].sum(), hist[9:13].sum(), hist[13:17].sum(), hist[17:].sum()))
     print("   resident:", " ".join(f"{v:5.0f}" for v in res))
     print("   live    :", " ".join(f"{v:5.0f}" for v in live))
