@@ -169,6 +169,8 @@ struct dpomp_handle {
     std::vector<double> wave_chain; // [T] mean over waves of the longest event chain in the wave, last call (-1 = unknown)
     int resident_wgs = 2048;        // workgroups of the compaction kernel the device holds at once (8 per CU)
     bool no_head_start = false;     // DPOMP_HEAD_START=0: experiment switch
+    double boost_frac = kBoostChainFrac;
+    int boost_wgs = 0;              // 0 = half of resident_wgs
     std::string err;
     // scratch for dpomp_pf_loglik
     dpomp_pop* scratch_pop = nullptr;
@@ -703,8 +705,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             a.boost_from = 0;
             if ((rpl == 16 || rpl == 32) && h->wave_chain[k] > 0.0 && !h->no_head_start) {
                 const int64_t n_wg = (p->P + kBlock - 1) / kBlock * B;
-                a.boost_from = (int32_t)std::max<int64_t>(0, n_wg - h->resident_wgs / 2);
-                a.boost_events = (int32_t)std::min(1.0e9, std::max(1.0, kBoostChainFrac * h->wave_chain[k]));
+                a.boost_from = (int32_t)std::max<int64_t>(0, n_wg - (h->boost_wgs ? h->boost_wgs : h->resident_wgs / 2));
+                a.boost_events = (int32_t)std::min(1.0e9, std::max(1.0, h->boost_frac * h->wave_chain[k]));
             }
 #ifdef DPOMP_TRACE_WG
             {
@@ -1217,8 +1219,16 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
             h->resident_wgs = cus * 8;  // 8 waves per SIMD, 4 SIMDs per CU, 4 waves per workgroup
-        const char* hs = getenv("DPOMP_HEAD_START");
-        h->no_head_start = hs && hs[0] == '0';
+        // experiment switch: DPOMP_HEAD_START=0 turns the head start off, DPOMP_HEAD_START=<frac>,<workgroups> sets the
+        // share of the event chain and the number of workgroups that get it (tools/size_probe.py)
+        if (const char* hs = getenv("DPOMP_HEAD_START")) {
+            double f = 0.0;
+            int n = 0;
+            const int got = sscanf(hs, "%lf,%d", &f, &n);
+            if (got >= 1 && f <= 0.0) h->no_head_start = true;
+            if (got >= 1 && f > 0.0) h->boost_frac = f;
+            if (got == 2 && n > 0) h->boost_wgs = n;
+        }
     }
     {   // device address of the static scratch array on THIS GPU (each device holds its own copy), once per device
         std::lock_guard<std::mutex> lock(g_scratch_mutex);
