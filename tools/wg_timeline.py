@@ -47,6 +47,11 @@ for k in range(n):
     per_cu = np.array([(cu == c).sum() for c in np.unique(cu)])
     print(f"   {len(ends)} CUs: workgroups per CU {per_cu.min()}..{per_cu.max()}, CU finishes at {ends.mean():6.1f} +- {ends.std():4.1f} us"
           f" (first {ends.min():.1f}, last {ends.max():.1f}): idle CU time before the launch ends {100 * (1 - ends.mean() / span):.1f} %")
+    first = (t0 - base) * TICK < 20.0  # workgroups dispatched when the launch begins
+    pro = (t1 - t0)[first] * TICK
+    print(f"   launch start: {first.sum()} workgroups dispatched within {((t0[first] - base) * TICK).max():.1f} us, their prologue "
+          f"{pro.mean():.1f} +- {pro.std():.1f} us (min {pro.min():.1f}, max {pro.max():.1f}); first event loop entered at "
+          f"{((t1 - base) * TICK).min():.1f} us, half of them by {np.median((t1[first] - base) * TICK):.1f} us")
     # time-weighted histogram, over all CUs, of the number of live waves on a CU (32 wave slots, 4 SIMDs)
     hist = np.zeros(34)
     for c in np.unique(cu):
