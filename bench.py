@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Benchmark of the particle-filter hot path (BASELINE.json metric: particle-steps/sec on
-Pooley SIS at 2^20 particles, plus log-ML error against the CPU reference path).
+"""Benchmark of the particle-filter hot path: particle-steps/sec on Pooley SIS at 2^20 particles,
+plus the log-ML error against the CPU reference path.
 
 One "step" = one full bootstrap particle filter call over the T = 5 Pooley observations with
 P = 2^20 particles per GPU (propagate -> weight -> log-mean-weight -> systematic resample, x5).
 N GPUs run N independent filters (one per rank, weak scaling) and all-gather their log-ML
-estimates over RCCL after every step -- the sharding BASELINE.json's north star prescribes for
-independent pMCMC chains / theta-particles.
+estimates over RCCL after every step -- independent pMCMC chains / theta-particles shard across
+GPUs and exchange nothing but these estimates.
 
 Prints ONE JSON line on rank 0.
 """

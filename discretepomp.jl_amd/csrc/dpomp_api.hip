@@ -38,7 +38,7 @@ typedef void (*PropFn)(PropArgs);
 
 constexpr int64_t kCompactionMinWaves = 4096;   // launches of at least this many waves run the compaction schedule
 constexpr int64_t kSmallFilterMaxWaves = 8192;  // calls of P <= 256 below this many waves run the whole-filter kernel
-constexpr int kDefaultPropVariant = 32;  // compaction every 32 events (-32 % on heterogeneous intervals)
+constexpr int kDefaultPropVariant = 32;  // workgroup compaction, first live-lane count after 32 events
 // Automatic schedule, per observation interval.  A launch that fills the chip (>= 8192 waves: the issue slots a
 // compaction frees are taken by other waves) runs with workgroup compaction unless, the last time this handle ran the
 // interval, a one-particle-per-lane schedule kept at least this fraction of the lanes busy (the kernels report that

@@ -1,6 +1,6 @@
 // dpomp_numerics.h -- the numerical spec shared by every kernel: counter-based
 // RNG streams, (0,1) uniforms, dlog/dexp, fixed-point weights and offspring
-// boundaries (DESIGN.md "Numerical spec").  Every routine is a fixed sequence
+// boundaries.  Every routine is a fixed sequence
 // of IEEE-754 double operations (fma = one rounding; the translation unit is
 // built with -ffp-contract=off so nothing else fuses), so a CPU evaluation of
 // the same spec gives the same bits.  Compiles for gfx950 (hipcc) and, for the

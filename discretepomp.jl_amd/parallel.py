@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of independent filters (SURVEY.md 8e).
+"""Multi-GPU sharding of independent filters.
 
 One particle filter does not shard (normalisation and resampling couple all its particles),
 but the callers run many independent ones: SMC^2 theta-particles (src/hmm_ibis.jl:53-56) and

@@ -42,7 +42,7 @@
  *   - randomness is explicit and counter-based: every draw is a pure function of
  *     (seed, global segment index, particle index, observation index, draw number),
  *     so results do not depend on call order, batch composition or how segments are
- *     sharded across GPUs.  See DESIGN.md "Numerical spec".
+ *     sharded across GPUs.
  */
 #ifndef DPOMP_H
 #define DPOMP_H
@@ -194,8 +194,8 @@ int dpomp_set_resampler(dpomp_handle* h, int rs_type);
  * observation (increment = LSE(carried + new) - LSE(carried)).  The carry state lives in the population handle. */
 int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac);
 
-/* Tuning: variant of the propagation kernel (DESIGN.md 4).  0 = library default (per observation interval: workgroup
- * compaction on a chip-filling launch unless the previous call measured a lane utilisation of 0.9 or more for that
+/* Tuning: variant of the propagation kernel.  0 = library default (per observation interval: workgroup
+ * compaction on a launch of at least 4096 waves unless the previous call measured a lane utilisation of 0.9 or more for that
  * interval, one particle per lane otherwise; see dpomp_get_lane_utilisation); 1 = one particle per lane; 2, 4 =
  * workgroup-local LDS queue with that many particles per lane and dynamic lane refill; 16, 32 = one particle per
  * lane with workgroup-level compaction every that many events.  Results do not depend on it. */
@@ -238,7 +238,7 @@ int dpomp_pop_gather(dpomp_handle* h, dpomp_pop* pop, const int64_t* ancestors);
  * population): installs the populations of accepted proposals, hmm_ibis.jl:109.  dst and src are
  * distinct handles of the same filter with equal P. */
 int dpomp_pop_take(dpomp_handle* h, dpomp_pop* dst, const dpomp_pop* src, const int64_t* take);
-/* Zero-copy interop (RCCL / torch.distributed population migration, SURVEY 8e): device pointer of the
+/* Zero-copy interop (RCCL / torch.distributed population migration): device pointer of the
  * populations as int32 [B][S][stride] (stride = P rounded up to 1024; lanes >= P are padding).
  * Valid until the next call on this population that resamples or gathers (those swap buffers).
  * for_write != 0 also marks the population initialised (the caller is about to fill it). */
@@ -264,7 +264,7 @@ int dpomp_simulate_events(dpomp_handle* h, const double* theta, int64_t P, uint6
 
 /* ---- inspection (parity tests, bench) ----------------------------------------- */
 #define DPOMP_DBG_LOGW 1          /* double[P]  log-weights of the last weighted observation */
-#define DPOMP_DBG_OFFSPRING_END 2 /* int32[P]   N_j of the last resampling       */
+#define DPOMP_DBG_OFFSPRING_END 2 /* int32[P]   offspring boundaries N_j of the last resampling */
 int dpomp_debug_download(dpomp_handle* h, const dpomp_pop* pop, int what, int64_t b, void* out);
 
 /* Device evaluation of the shared numerics for n inputs: uniforms of particle-stream

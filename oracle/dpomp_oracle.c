@@ -21,7 +21,7 @@
  *       as a serial left fold (hmm_particle_filter.jl:29-30), `log(cw[end]/P)`
  *       (:60), and rsp_systematic verbatim (hmm_pf_resample.jl:24-42).
  *   ORC_MODE_SPEC      the numerical spec the HIP kernels implement
- *       (DESIGN.md "Numerical spec"): same propagation, but elementary
+ *       (discretepomp.jl_amd/csrc/dpomp_numerics.h): same propagation, but elementary
  *       functions dlog/dexp restated below (so CPU and GPU agree to the bit),
  *       max-shifted weights held as 64-bit fixed point (so the sum and scan
  *       are associative and every partition gives the same bits), offspring

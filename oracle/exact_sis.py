@@ -71,7 +71,7 @@ if __name__ == "__main__":
 
 def exact_evidence(lower, upper, x0=(100, 1), times=POOLEY_TIMES, cases=POOLEY_CASES, n=40, sigma=2.0):
     """-ln p(y) and posterior means under a uniform prior on [lower, upper] (2-D), by midpoint quadrature
-    of the exact likelihood on an n x n grid (SURVEY.md 8c: 20.1676, beta 0.003246, gamma 0.10832 for
+    of the exact likelihood on an n x n grid (20.1676, beta 0.003246, gamma 0.10832 for
     U(0,0.01) x U(0,0.5), the prior of test/runtests.jl:29)."""
     import numpy as _np
     bs = lower[0] + (upper[0] - lower[0]) * (_np.arange(n) + 0.5) / n

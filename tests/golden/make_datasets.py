@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Synthetic data sets for BASELINE.json configs 3-5 (the reference ships data only for Pooley SIS).
+"""Synthetic data sets for the SEIR and Lotka-Volterra benchmark configurations (the reference ships data only for
+Pooley SIS).
 
-Recipe (BASELINE.md "Inputs"): simulate with the framework's own simulator (here: the CPU oracle's, which the
+Recipe: simulate with the framework's own simulator (here: the CPU oracle's, which the
 GPU simulator equals event for event), observation = state (the reference's default dmy_obs_fn), written in the
 reference's CSV dialect (header, ", " separators).  Seed policy: first seed >= 20261003 whose trajectory is a real
 outbreak (SEIR: final R >= 50; an extinct epidemic makes a degenerate benchmark).

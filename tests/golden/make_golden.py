@@ -49,7 +49,7 @@ def main():
     out["cases"].append(case("pooley_sis_p1000_ragged", sis, pooley, (0.0032, 0.09), 1000, 20261003))
     seir = dp.generate_model("SEIR", [100, 0, 1, 0])
     th = (0.005, 0.2, 0.1)
-    y = simulated_obs(seir, th, [20.0, 40.0, 60.0, 80.0, 100.0], 20261003)  # BASELINE config 3 data recipe
+    y = simulated_obs(seir, th, [20.0, 40.0, 60.0, 80.0, 100.0], 20261003)  # the SEIR benchmark data recipe (make_datasets.py)
     out["cases"].append(case("seir_synthetic_p1024", seir, y, th, 1024, 3))
     lv = dp.generate_model("LOTKA", [70, 70])
     th = (0.5, 0.0025, 0.3)

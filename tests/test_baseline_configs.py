@@ -1,4 +1,5 @@
-"""BASELINE configs 3, 4 and 5 at their own workload (one GPU's share of it), through the drivers that name them:
+"""The SEIR and Lotka-Volterra benchmark configurations (3, 4 and 5 of the benchmark list) at their own workload (one
+GPU's share of it), through the drivers that name them:
 
   3  SEIR, 2^18 particles, 4-chain particle-marginal MH                   (run_pmcmc_analysis)
   4  SEIR, run_smc2 with 512 theta-particles x 2^16 over 8 GPUs           (one rank's share: 64 x 2^16, run_pibis)

@@ -226,7 +226,7 @@ def test_simulate_matches_oracle(dp, orc, pooley):
     pf.close()
 
 
-# ---- full size (BASELINE config 2): properties that do not need the oracle at 2^20 ---------------
+# ---- full size (the headline benchmark: Pooley SIS, 2^20 particles): properties that need no oracle ----
 def test_full_size_pooley_2pow20(sis, dp):
     P = 1 << 20
     theta = [0.003, 0.1]
@@ -326,7 +326,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 @pytest.mark.parametrize("name,x0,theta,csv", [("SEIR", [100, 0, 1, 0], [0.005, 0.2, 0.1], "seir_synthetic.csv"),
                                                ("LOTKA", [70, 70], [0.5, 0.0025, 0.3], "lotka_synthetic.csv")])
 def test_baseline_config_shapes_at_scale(dp, orc, name, x0, theta, csv):
-    """BASELINE configs 3-5 on their committed synthetic data: exact parity at P = 512, then a large batched run
+    """The SEIR / Lotka-Volterra benchmark models on their committed synthetic data: exact parity at P = 512, then a large batched run
     (4 x 2^16) whose estimates must agree with each other within Monte-Carlo scatter and raise no status flag."""
     y = dp.get_observations(os.path.join(GOLDEN_DIR, csv))
     pf = dp.ParticleFilter(dp.generate_model(name, x0), y)

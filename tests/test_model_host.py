@@ -73,7 +73,7 @@ def test_choose_event_strict_greater_and_fallthrough(orc):
 def test_gaussian_obs_model(dp, orc):
     om = dp.partial_gaussian_obs_model(2.0, seq=2)
     y = dp.Observation(20.0, 1, 1.0, [0, 18])
-    assert om(y, [83, 18], None) == pytest.approx(-1.612085713764618, abs=1e-15)  # tmp1
+    assert om(y, [83, 18], None) == pytest.approx(-1.612085713764618, abs=1e-15)  # tmp1 of src/hmm_examples.jl:61 for sigma = 2
     assert om(y, [81, 20], None) == pytest.approx(-1.612085713764618 - 4 / 8)
     model = dp.generate_model("SIS", [100, 1])
     desc = dp.ModelDescriptor(model, [y])

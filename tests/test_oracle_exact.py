@@ -1,5 +1,5 @@
 """Pins the oracle at distribution level: the exact CTMC forward-algorithm likelihood of the
-Pooley SIS data (SURVEY.md 8c known answers) and the PF's unbiasedness on the likelihood scale."""
+Pooley SIS data and the PF's unbiasedness on the likelihood scale."""
 import math
 
 import numpy as np
@@ -8,7 +8,7 @@ import pytest
 from helpers import threaded
 from oracle import exact_sis
 
-KNOWN = {  # SURVEY.md 8(c), re-derived by oracle/exact_sis.py
+KNOWN = {  # exact log-likelihoods, re-derived by oracle/exact_sis.py
     (0.003, 0.1): -15.6873794556,
     (0.0032, 0.1): -16.0197707226,
     (0.0025, 0.08): -15.4530158001,
@@ -54,7 +54,7 @@ def test_exact_agrees_with_uniformisation():
 @pytest.mark.parametrize("mode", ["spec", "faithful"])
 def test_pf_is_unbiased_on_the_likelihood_scale(dp, orc, pooley, mode):
     """E[exp(ll_hat)] = p(y | theta): log mean_r exp(ll_r) within 3.5 standard errors of exact, and
-    mean(ll_r) below exact by about Var/2 (Jensen).  BASELINE config 1: P = 1024, seeds 1..R."""
+    mean(ll_r) below exact by about Var/2 (Jensen).  The CPU-runnable benchmark configuration: P = 1024, seeds 1..R."""
     desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), pooley)
     theta = (0.003, 0.1)
     R = 160
@@ -91,10 +91,10 @@ def test_spec_mode_tracks_reference_faithful_mode(dp, orc, pooley):
     assert diff_slots <= 2  # ancestors may differ only where u_i falls within rounding of a boundary
 
 
-def test_events_per_particle_matches_survey_expectation(dp, orc, pooley):
+def test_events_per_particle_matches_the_exact_expectation(dp, orc, pooley):
     desc = dp.ModelDescriptor(dp.generate_model("SIS", [100, 1]), pooley)
     r = orc.pf_loglik(desc, 8192, (0.003, 0.1), seed=3)
-    assert 1050 < r.events / 8192 < 1120  # ~1085 events per particle per PF call
+    assert 1050 < r.events / 8192 < 1120  # ~1085 events per particle per PF call (exact expectation under the filtered law)
 
 
 @pytest.mark.parametrize("rs_type", [2, 3])

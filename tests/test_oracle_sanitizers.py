@@ -1,4 +1,4 @@
-"""The CPU restatement under AddressSanitizer + UBSan (GPU sanitizers are not available on the pool)."""
+"""The CPU restatement under AddressSanitizer + UBSan (GPU sanitizers are not available on the GPU pool)."""
 import os
 import subprocess
 

@@ -60,7 +60,7 @@ def test_rejection_sample_and_sre_helpers(dp):
 
 @pytest.mark.gpu
 def test_pmmh_on_gpu_four_chains(dp, pooley):
-    """BASELINE config-3 shape on the Pooley data: 4 chains, batched proposals, one filter call per iteration."""
+    """The 4-chain PMMH benchmark shape on the Pooley data: 4 chains, batched proposals, one filter call per iteration."""
     model = dp.generate_model("SIS", [100, 1])
     model.prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
     init = np.array([[0.003, 0.0035, 0.0028, 0.004], [0.1, 0.12, 0.09, 0.14]])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where a filter call's time goes on the single-GPU shapes of the BASELINE configs: wall time per call without
+"""Where a filter call's time goes on the single-GPU shapes of the benchmark configurations (Pooley SIS 2^20, SEIR 4 x 2^18,
+SEIR 64 x 2^16, Lotka-Volterra 2^20, SIS 4000 x 200): wall time per call without
 profiling, then per-kernel average durations (HIP events carrying each kernel's own begin and end) and their sum.
 Usage: python tools/config_profile.py [reps]   -> JSON on stdout."""
 import json

@@ -16,7 +16,7 @@ HBM_PEAK, HBM_MEASURED_COPY = 8000.0, 6290.0   # GB/s: spec, and the measured fl
 
 
 def moved_bytes(P, S, B):
-    """HBM bytes each kernel has to move per launch with int32 state (what is in memory), per DESIGN.md's layout:
+    """HBM bytes each kernel has to move per launch with int32 state (what is in memory):
     k_wsum reads logw and writes the fixed-point weights; k_offsets reads those and writes N_j (int32); k_gather reads
     N_j, gathers and writes the state."""
     n = P * B

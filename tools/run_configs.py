@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Runs the single-GPU shapes of BASELINE.json configs 3-5 (synthetic data per BASELINE.md: simulated with this
-framework's own simulator, seed 20261003) and prints timings.  Not part of the test suite."""
+"""Runs the single-GPU shapes of the SEIR and Lotka-Volterra benchmark configurations (synthetic data simulated with
+this framework's own simulator, seed 20261003: tests/golden/make_datasets.py) and prints timings.  Not part of the test suite."""
 import json
 import sys
 import time

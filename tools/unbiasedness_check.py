@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpomp_amd as dp  # noqa: E402
 
 EXACT = {(0.003, 0.1): -15.6873794556, (0.0032, 0.1): -16.0197707226, (0.0025, 0.08): -15.4530158001,
-         (0.004, 0.15): -17.3813549614}   # SURVEY.md 8c, re-derived by oracle/exact_sis.py (tests/test_oracle_exact.py)
+         (0.004, 0.15): -17.3813549614}   # exact values, re-derived by oracle/exact_sis.py (tests/test_oracle_exact.py)
 
 
 def main():
