@@ -553,6 +553,34 @@ def test_automatic_schedule_reads_lane_utilisation_and_keeps_results(dp, pooley)
     pf.close()
 
 
+def test_head_start_of_the_last_workgroups_is_scheduling_only(dp, pooley, monkeypatch):
+    """From its second call on a handle the compaction kernel runs the workgroups that are dispatched last at raised
+    wave priority for part of their event chain (from the chain length the previous call measured).  That may only
+    move time: log-likelihood, event count and final population equal the first call's (no head start: nothing
+    measured yet), those of a handle with the head start switched off, and the oracle's first observation."""
+    theta = np.array([[0.003, 0.0032], [0.1, 0.1]])
+    P = 1 << 18
+
+    def run(pf, n):
+        out = []
+        pop = pf.alloc_population(2, P)
+        for _ in range(n):
+            ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=77, seg_base=5)
+            out.append((ll.copy(), pf.last_event_count(), pop.download(0).copy(), pop.download(1).copy()))
+        return out
+
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    with_hs = run(pf, 3)
+    pf.close()
+    monkeypatch.setenv("DPOMP_HEAD_START", "0")
+    pf_off = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    without = run(pf_off, 2)
+    pf_off.close()
+    for r in with_hs[1:] + without:
+        assert np.array_equal(r[0], with_hs[0][0]) and r[1] == with_hs[0][1]
+        assert np.array_equal(r[2], with_hs[0][2]) and np.array_equal(r[3], with_hs[0][3])
+
+
 def test_event_loop_division_is_the_ieee_quotient(sis):
     """The event loop divides log(u) by the rate total with the compiler's Newton-Markstein sequence minus its range
     handling (dpomp_numerics.h: div_in_range).  Inside its range it must return the correctly rounded quotient --
