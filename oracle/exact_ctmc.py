@@ -27,8 +27,36 @@ import math
 import numpy as np
 import scipy.sparse as sp
 
+def _n(x):
+    return x.sum(1)
+
+
 # (rate function over an array of states [n, S] -> [n, E]; transition matrix [E, S]; 0-based observed component)
+# Names ending in _FD are the frequency-dependent variants (src/hmm_examples.jl:126-144: the infection rate divided by
+# the population size).
 MODELS = {
+    "SI": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1]], 1), np.array([[-1, 1]]), 1),          # si_rf :103-105, :173
+    "SI_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1] / _n(x)], 1), np.array([[-1, 1]]), 1),  # si_rf_fd :126-128
+    "SIR_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1] / _n(x), th[1] * x[:, 1]], 1),        # sir_rf_fd :130-133
+               np.array([[-1, 1, 0], [0, -1, 1]]), 1),
+    "SIS_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1] / _n(x), th[1] * x[:, 1]], 1),
+               np.array([[-1, 1], [1, -1]]), 1),
+    "SEI": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 2], th[1] * x[:, 1]], 1),                  # sei_rf :112-115, :185-186
+            np.array([[-1, 1, 0], [0, -1, 1]]), 2),
+    "SEI_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 2] / _n(x), th[1] * x[:, 1]], 1),        # sei_rf_fd :135-138
+               np.array([[-1, 1, 0], [0, -1, 1]]), 2),
+    "SEIR_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 2] / _n(x), th[1] * x[:, 1], th[2] * x[:, 2]], 1),  # :140-144
+                np.array([[-1, 1, 0, 0], [0, -1, 1, 0], [0, 0, -1, 1]]), 2),
+    "SEIS": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 2], th[1] * x[:, 1], th[2] * x[:, 2]], 1),  # seir_rf, :193-194
+             np.array([[-1, 1, 0], [0, -1, 1], [1, 0, -1]]), 2),
+    "SEIS_FD": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 2] / _n(x), th[1] * x[:, 1], th[2] * x[:, 2]], 1),
+                np.array([[-1, 1, 0], [0, -1, 1], [1, 0, -1]]), 2),
+    # rossmac_rf :159-168, m_transition :203 (mosquito birth / deaths, human and mosquito infection, human recovery);
+    # the mosquito population is unbounded: box-truncated like LOTKA (0/0 -> rate 0 where a denominator vanishes)
+    "ROSSMAC": (lambda th, x: np.stack([th[0] * (x[:, 2] + x[:, 3]), th[0] * x[:, 2], th[0] * x[:, 3],
+                                        th[1] * _safe_div(x[:, 0] * x[:, 3], x[:, 0] + x[:, 1]),
+                                        th[2] * _safe_div(x[:, 1] * x[:, 2], x[:, 2] + x[:, 3]), th[3] * x[:, 1]], 1),
+                np.array([[0, 0, 1, 0], [0, 0, -1, 0], [0, 0, 0, -1], [-1, 1, 0, 0], [0, 0, -1, 1], [1, -1, 0, 0]]), 1),
     "SIS": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1], th[1] * x[:, 1]], 1),
             np.array([[-1, 1], [1, -1]]), 1),
     "SIR": (lambda th, x: np.stack([th[0] * x[:, 0] * x[:, 1], th[1] * x[:, 1]], 1),
@@ -40,6 +68,10 @@ MODELS = {
 }
 
 
+def _safe_div(a, b):
+    return np.divide(a, b, out=np.zeros_like(a, dtype=float), where=b != 0)
+
+
 def _encode(x, base):
     key = np.zeros(x.shape[0], dtype=np.int64)
     for s in range(x.shape[1]):
@@ -49,9 +81,12 @@ def _encode(x, base):
 
 def reachable_states(trans, x0, rate_fn, bound=None):
     """All states reachable from x0 through events of positive rate (for SOME positive theta: the structure of the
-    catalogue's rate functions does not depend on theta), component-wise within [0, bound]."""
+    catalogue's rate functions does not depend on theta), component-wise within [0, bound] (bound: a scalar or one
+    limit per component)."""
     S = len(x0)
-    base = int(bound if bound is not None else sum(x0)) + 2
+    if bound is not None:
+        bound = np.asarray(bound)  # a scalar, or one upper limit per component
+    base = int(bound.max() if bound is not None else sum(x0)) + 2
     ones = np.ones(8)
     known = np.array([x0], dtype=np.int64)
     frontier = known
@@ -78,6 +113,8 @@ def reachable_states(trans, x0, rate_fn, bound=None):
 def generator(model, theta, x0, bound=None):
     """(states [n, S], sparse Q^T over n states + one absorbing leak state, total exit rates)."""
     rate_fn, trans, _ = MODELS[model]
+    if bound is not None:
+        bound = np.asarray(bound)
     states, keys, base = reachable_states(trans, list(x0), rate_fn, bound)
     n = len(states)
     th = np.zeros(8)

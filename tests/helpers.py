@@ -94,3 +94,29 @@ def synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99, obs_ids=None)
     traj = orc.simulate(d, 1, theta, seed=seed)  # [T][S][1]
     ids = obs_ids or [1] * T
     return [dp.Observation(t, ids[i], 1.0, [int(v) for v in traj[i, :, 0]]) for i, t in enumerate(times)]
+
+
+# ---- exact likelihood of a catalogue case (oracle/exact_ctmc.py: sparse generator + uniformisation) -------------------
+ROSSMAC_EXACT_X0, ROSSMAC_EXACT_BOUND = [50, 5, 60, 8], [55, 55, 130, 60]  # mosquito box: leaked mass < 1e-14
+_EXACT_CACHE = {}
+
+
+def catalogue_case_exact(dp, orc, name, x0, fd, theta):
+    """(model, observations, exact log p(y | theta)) of one catalogue case on data simulated by the oracle's simulator
+    (4 observations up to t = 20, y.val = state).  Ross-Macdonald's mosquito population is unbounded, so its exact
+    value is computed from a smaller initial condition on a box that holds all but 1e-14 of the probability mass."""
+    from oracle import exact_ctmc
+    key = (name, bool(fd))
+    if key not in _EXACT_CACHE:
+        bound = None
+        if name == "ROSSMAC":
+            x0, bound = ROSSMAC_EXACT_X0, ROSSMAC_EXACT_BOUND
+        model = dp.generate_model(name, x0, freq_dep=fd)
+        y = synthetic_data(dp, orc, model, theta)
+        mkey = name + ("_FD" if fd else "")
+        comp = exact_ctmc.MODELS[mkey][2]
+        r = exact_ctmc.exact_loglik(mkey, theta, x0, [o.time for o in y], [o.val[comp] for o in y], bound=bound)
+        assert r["leak"] < 1e-12 and r["truncation"] < 1e-12
+        _EXACT_CACHE[key] = (model, y, r["ll"])
+    return _EXACT_CACHE[key]
+

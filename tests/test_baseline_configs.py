@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from helpers import OracleBank
+from helpers import CATALOGUE_CASES, OracleBank, catalogue_case_exact
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,22 @@ def test_gpu_filter_is_unbiased_against_the_exact_lotka_likelihood(dp, lotka_dat
     ratio = np.exp(lls - g["ll"])
     se = ratio.std(ddof=1) / math.sqrt(B)
     assert abs(ratio.mean() - 1.0) < 4 * se and se < 0.02, (ratio.mean(), se)
+    pf.close()
+
+
+@pytest.mark.parametrize("name,x0,fd,theta", [c for c in CATALOGUE_CASES if c[0] != "LOTKA"])
+def test_gpu_filter_is_unbiased_against_the_exact_likelihood_of_every_catalogue_model(dp, orc, name, x0, fd, theta):
+    """Every catalogue model, density and frequency dependent, through its compiled evaluator on the GPU: 4096 filters
+    of 1024 particles against the exact likelihood from a generator built from the reference's rate function,
+    transition matrix and observed component alone (src/hmm_examples.jl:103-204) -- no random number, no oracle RNG."""
+    model, y, exact = catalogue_case_exact(dp, orc, name, x0, fd, theta)
+    pf = dp.ParticleFilter(model, y)
+    B = 4096
+    lls = pf.loglik(np.tile(np.array(theta, dtype=float)[:, None], (1, B)), 1024, seed=4300)
+    assert np.all(np.isfinite(lls)) and np.all(pf.last_status == 0)
+    ratio = np.exp(lls - exact)
+    se = ratio.std(ddof=1) / math.sqrt(B)
+    assert abs(ratio.mean() - 1.0) < 4 * se and se < 0.003, (name, fd, ratio.mean(), se)
     pf.close()
 
 

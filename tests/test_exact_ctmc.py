@@ -1,6 +1,7 @@
 """RNG-independent pins beyond Pooley SIS: exact CTMC likelihoods of the SEIR and Lotka-Volterra data sets
-(oracle/exact_ctmc.py, golden values in tests/golden/exact_ctmc.json made by tests/golden/make_exact_ctmc.py), the
-oracle's unbiasedness against them in both of its modes, and the SPEC <-> FAITHFUL bound on every catalogue model."""
+(oracle/exact_ctmc.py, golden values in tests/golden/exact_ctmc.json made by tests/golden/make_exact_ctmc.py) and of
+every other catalogue model on simulated data, the oracle's unbiasedness against them, and the SPEC <-> FAITHFUL
+bound on every catalogue model."""
 import json
 import math
 import os
@@ -9,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from helpers import CATALOGUE_CASES, synthetic_data, threaded
+from helpers import CATALOGUE_CASES, catalogue_case_exact, synthetic_data, threaded
 from oracle import exact_ctmc, exact_sis
 
 EXACT = json.load(open(os.path.join(GOLDEN, "exact_ctmc.json")))
@@ -65,6 +66,34 @@ def test_oracle_is_unbiased_against_the_exact_lotka_likelihood(dp, orc):
     ratio = np.exp(lls - g["ll"])
     se = ratio.std(ddof=1) / math.sqrt(R)
     assert abs(ratio.mean() - 1.0) < 3.5 * se, (ratio.mean(), se)
+
+
+@pytest.mark.parametrize("name,x0,fd,theta", [c for c in CATALOGUE_CASES if c[0] != "LOTKA"])
+def test_oracle_is_unbiased_against_the_exact_likelihood_of_every_catalogue_model(dp, orc, name, x0, fd, theta):
+    """E[exp(ll_hat)] = p(y | theta) with the exact value from a generator built directly from the reference's rate
+    function, transition matrix and observed component (src/hmm_examples.jl:103-204): pins every catalogue model --
+    density and frequency dependent -- in the oracle without any random number.  (Lotka-Volterra: above.)"""
+    model, y, exact = catalogue_case_exact(dp, orc, name, x0, fd, theta)
+    desc = dp.ModelDescriptor(model, y)
+    R = 128
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 512, theta, seed=s + 1).ll, R))
+    ratio = np.exp(lls - exact)
+    se = ratio.std(ddof=1) / math.sqrt(R)
+    assert abs(ratio.mean() - 1.0) < 4.0 * se and se < 0.03, (ratio.mean(), se)
+
+
+def test_exact_likelihood_tells_the_catalogue_variants_apart(dp, orc):
+    """The pin has teeth: on the same data the frequency-dependent rate function, a wrong observed component or the
+    SEIS transition matrix in place of SEIR's move the exact value by far more than the test above tolerates."""
+    from oracle import exact_ctmc
+    model, y, exact = catalogue_case_exact(dp, orc, "SEI", [100, 0, 1], False, [0.005, 0.2])
+    t, v2, v1 = [o.time for o in y], [o.val[2] for o in y], [o.val[1] for o in y]
+    fd = exact_ctmc.exact_loglik("SEI_FD", [0.005, 0.2], [100, 0, 1], t, v2)["ll"]
+    wrong_comp = exact_ctmc.exact_loglik("SEI", [0.005, 0.2], [100, 0, 1], t, v1)["ll"]
+    assert abs(fd - exact) > 1.0 and abs(wrong_comp - exact) > 0.2
+    _, y2, e2 = catalogue_case_exact(dp, orc, "SEIS", [100, 0, 1], False, [0.005, 0.2, 0.1])
+    as_sei = exact_ctmc.exact_loglik("SEI", [0.005, 0.2], [100, 0, 1], [o.time for o in y2], [o.val[2] for o in y2])["ll"]
+    assert abs(as_sei - e2) > 0.05
 
 
 @pytest.mark.parametrize("name,x0,fd,theta", CATALOGUE_CASES)
