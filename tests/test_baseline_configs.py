@@ -90,6 +90,19 @@ def test_gpu_filter_is_unbiased_against_the_exact_likelihood_of_every_catalogue_
     pf.close()
 
 
+def test_gpu_filter_is_unbiased_with_unknown_initial_time_and_an_unweighted_row(dp, make_obs):
+    """t0_index and an obs_id = 0 row on the GPU against the exact likelihood (see tests/test_exact_ctmc.py)."""
+    from test_exact_ctmc import T0_CASE, t0_case_exact, t0_case_model
+    c = T0_CASE
+    pf = dp.ParticleFilter(t0_case_model(dp), make_obs(c["times"], c["vals"], obs_ids=c["obs_ids"]))
+    B = 4096
+    lls = pf.loglik(np.tile(np.array(c["theta"])[:, None], (1, B)), 1024, seed=4400)
+    ratio = np.exp(lls - t0_case_exact())
+    se = ratio.std(ddof=1) / math.sqrt(B)
+    assert abs(ratio.mean() - 1.0) < 4 * se and se < 0.004, (ratio.mean(), se)
+    pf.close()
+
+
 # ---- config 3: SEIR, 4-chain PMMH, 2^18 particles -----------------------------------------------------------------
 def test_config3_pmmh_chains_equal_the_oracle_driven_chains(dp, orc, seir_data):
     """Same driver, same seeds, 512 particles: every sample of every chain identical."""

@@ -96,6 +96,37 @@ def test_exact_likelihood_tells_the_catalogue_variants_apart(dp, orc):
     assert abs(as_sei - e2) > 0.05
 
 
+T0_CASE = dict(times=[20.0, 30.0, 40.0, 60.0], vals=[[0, 18], [0, 0], [0, 65], [0, 70]], obs_ids=[1, 0, 1, 1],
+               theta=[0.003, 0.1, 4.5])
+
+
+def t0_case_model(dp):
+    rf = dp.RateFunction([dp.RateTerm(1, ((1,), (2,))), dp.RateTerm(2, ((2,),))])
+    return dp.generate_custom_model("SIS", rf, [100, 1], [[-1, 1], [1, -1]], t0_index=3)
+
+
+def t0_case_exact():
+    c = T0_CASE
+    return exact_ctmc.exact_loglik("SIS", c["theta"][:2], [100, 1], c["times"], [v[1] for v in c["vals"]], t0=c["theta"][2],
+                                   obs_ids=c["obs_ids"])["ll"]
+
+
+def test_oracle_is_unbiased_with_unknown_initial_time_and_an_unweighted_row(dp, orc, make_obs):
+    """t0_index (the trajectory starts at theta[3], src/hmm_particle_filter.jl:45-47) and an obs_id = 0 row (propagate
+    only, :58) against the exact likelihood with the same start time and the same row skipped."""
+    c = T0_CASE
+    desc = dp.ModelDescriptor(t0_case_model(dp), make_obs(c["times"], c["vals"], obs_ids=c["obs_ids"]))
+    exact = t0_case_exact()
+    R = 160
+    lls = np.array(threaded(lambda s: orc.pf_loglik(desc, 1024, c["theta"], seed=s + 1).ll, R))
+    ratio = np.exp(lls - exact)
+    se = ratio.std(ddof=1) / math.sqrt(R)
+    assert abs(ratio.mean() - 1.0) < 4.0 * se and se < 0.03, (ratio.mean(), se)
+    # the start time matters: the exact value for t0 = 0 is far away
+    assert abs(exact_ctmc.exact_loglik("SIS", c["theta"][:2], [100, 1], c["times"], [v[1] for v in c["vals"]],
+                                       obs_ids=c["obs_ids"])["ll"] - exact) > 0.1
+
+
 @pytest.mark.parametrize("name,x0,fd,theta", CATALOGUE_CASES)
 def test_spec_mode_tracks_faithful_mode_on_every_catalogue_model(dp, orc, name, x0, fd, theta):
     """SPEC (what the GPU computes) against FAITHFUL (the reference's Float64 left fold, libm log/exp, rsp_systematic
