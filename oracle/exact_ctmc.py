@@ -165,6 +165,18 @@ def _expm_apply(QT, lam, t, v, tol=1e-13):
     return acc, max(0.0, 1.0 - mass)
 
 
+def transient_distribution(model, theta, x0, t, bound=None, t0=0.0):
+    """P(X(t) = x | X(t0) = x0) over the reachable states: (states [n, S], probabilities [n], mass that left the box).
+    The law the forward simulation and the filter's propagation step sample from."""
+    states, QT, tot = generator(model, theta, x0, bound)
+    n = len(states)
+    lam = float(tot.max()) * 1.02 + 1e-12
+    alpha = np.zeros(n + 1)
+    alpha[int(np.flatnonzero((states == np.asarray(x0)).all(1))[0])] = 1.0
+    alpha, _ = _expm_apply(QT, lam, float(t) - t0, alpha)
+    return states, alpha[:n], float(alpha[n])
+
+
 def exact_loglik(model, theta, x0, obs_times, obs_values, sigma=2.0, bound=None, t0=0.0, obs_ids=None):
     """Returns dict(ll, increments, n_states, leak, truncation).  obs_values[t] = the observed count that the
     Gaussian emission compares with the model's observed component (sum(y.val[y_seq]) of the reference)."""

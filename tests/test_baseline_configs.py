@@ -90,6 +90,31 @@ def test_gpu_filter_is_unbiased_against_the_exact_likelihood_of_every_catalogue_
     pf.close()
 
 
+@pytest.mark.parametrize("name,x0,theta,t,bound", [("SIS", [100, 1], [0.003, 0.1], 30.0, None), ("SIR", [100, 1, 0], [0.003, 0.1], 25.0, None),
+                                                   ("SEIS", [100, 0, 1], [0.005, 0.2, 0.1], 20.0, None),
+                                                   ("SEIR", [100, 0, 1, 0], [0.005, 0.2, 0.1], 30.0, None),
+                                                   ("LOTKA", [70, 70], [0.5, 0.0025, 0.3], 3.0, 400)])
+def test_gpu_propagation_samples_the_exact_transient_law(dp, make_obs, name, x0, theta, t, bound):
+    """2^20 particles through two unweighted rows (no weights, no resampling: independent trajectories, gathered
+    through the compaction schedule) against exp(Q t) applied to the initial condition: a chi-square test over every
+    state with an expected count of 25 or more.  Pins the event loop -- waiting times, event choice, transitions, the
+    stream per particle -- on the GPU without reference to the oracle's random numbers."""
+    from oracle import exact_ctmc
+    from test_exact_ctmc import chi_square_against_exact
+    pf = dp.ParticleFilter(dp.generate_model(name, x0), make_obs([t / 2, t], [[0] * len(x0)] * 2, obs_ids=[0, 0]))
+    P = 1 << 20
+    pop = pf.alloc_population(1, P)
+    pf.partial_log_likelihood(pop, np.array(theta, dtype=float)[:, None], 1, 2, seed=12)
+    assert pf.last_status[0] == 0
+    final = pop.download(0)
+    states, probs, leak = exact_ctmc.transient_distribution(name, theta, x0, t, bound=bound)
+    assert leak < 1e-9
+    keys, cnt = np.unique(final, axis=0, return_counts=True)
+    stat, df = chi_square_against_exact({tuple(k): c for k, c in zip(keys, cnt)}, states, probs, P)
+    assert df > 30 and abs(stat - df) < 5.0 * math.sqrt(2.0 * df), (name, stat, df)
+    pf.close()
+
+
 def test_gpu_filter_is_unbiased_with_unknown_initial_time_and_an_unweighted_row(dp, make_obs):
     """t0_index and an obs_id = 0 row on the GPU against the exact likelihood (see tests/test_exact_ctmc.py)."""
     from test_exact_ctmc import T0_CASE, t0_case_exact, t0_case_model

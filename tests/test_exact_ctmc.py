@@ -96,6 +96,35 @@ def test_exact_likelihood_tells_the_catalogue_variants_apart(dp, orc):
     assert abs(as_sei - e2) > 0.05
 
 
+def chi_square_against_exact(counts_by_state, states, probs, n, min_expected=25.0):
+    """(statistic, degrees of freedom) of observed state counts against the exact law; states with small expected
+    counts are pooled into one cell."""
+    expected = probs * n
+    big = expected >= min_expected
+    obs = np.array([counts_by_state.get(tuple(s), 0) for s in states], dtype=float)
+    o = np.append(obs[big], obs[~big].sum() + (n - obs.sum()))
+    e = np.append(expected[big], expected[~big].sum() + n * max(0.0, 1.0 - probs.sum()))
+    keep = e > 0
+    return float((((o - e) ** 2) / np.where(keep, e, 1.0))[keep].sum()), int(keep.sum()) - 1
+
+
+@pytest.mark.parametrize("name,x0,theta,t", [("SIS", [100, 1], [0.003, 0.1], 30.0), ("SIR", [100, 1, 0], [0.003, 0.1], 25.0),
+                                             ("SEIS", [100, 0, 1], [0.005, 0.2, 0.1], 20.0)])
+def test_oracle_propagation_samples_the_exact_transient_law(dp, orc, make_obs, name, x0, theta, t):
+    """The Gillespie propagation on its own: with unweighted rows (obs_id = 0: no weights, no resampling) the particles
+    of a filter are independent trajectories, so their states at time t must follow exp(Q t) applied to the initial
+    condition -- computed without random numbers from the reference's rate function and transition matrix."""
+    y = make_obs([t / 2, t], [[0] * len(x0)] * 2, obs_ids=[0, 0])
+    desc = dp.ModelDescriptor(dp.generate_model(name, x0), y)
+    P = 40000
+    r = orc.pf_loglik(desc, P, theta, seed=11, nthreads=8)
+    states, probs, leak = exact_ctmc.transient_distribution(name, theta, x0, t)
+    assert leak == 0.0 and abs(probs.sum() - 1.0) < 1e-9
+    keys, cnt = np.unique(r.pop, axis=0, return_counts=True)
+    stat, df = chi_square_against_exact({tuple(k): c for k, c in zip(keys, cnt)}, states, probs, P)
+    assert df > 10 and abs(stat - df) < 5.0 * math.sqrt(2.0 * df), (stat, df)
+
+
 T0_CASE = dict(times=[20.0, 30.0, 40.0, 60.0], vals=[[0, 18], [0, 0], [0, 65], [0, 70]], obs_ids=[1, 0, 1, 1],
                theta=[0.003, 0.1, 4.5])
 
