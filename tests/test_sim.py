@@ -69,3 +69,26 @@ def test_simulation_truncates_at_max_events(dp, orc):
     for i in range(64):
         assert np.array_equal(times[i], ref[i][1]) and np.array_equal(types[i], ref[i][2])
     pf.close()
+
+
+@pytest.mark.gpu
+def test_simulator_samples_the_exact_transient_law(dp):
+    """30 000 forward simulations (the recording kernel behind gillespie_sim): the states at both observation times
+    against exp(Q t) applied to the initial condition (chi-square over every state with an expected count >= 25) and
+    the number of recorded events against the event count the states imply (SIS: infections - recoveries = I - 1)."""
+    from oracle import exact_ctmc
+    from test_exact_ctmc import chi_square_against_exact
+    theta, x0, n = [0.003, 0.1], [100, 1], 30000
+    pf = dp.ParticleFilter(dp.generate_model("SIS", x0), dp.generate_observations(30.0, 2, 2))
+    counts, times, types, states = pf.simulate_events(theta, n_sims=n, seed=5, max_events=2000)
+    assert (counts >= 0).all()
+    for k, t in enumerate((15.0, 30.0)):
+        st, pr, leak = exact_ctmc.transient_distribution("SIS", theta, x0, t)
+        keys, cnt = np.unique(states[k].T, axis=0, return_counts=True)
+        stat, df = chi_square_against_exact({tuple(a): c for a, c in zip(keys, cnt)}, st, pr, n)
+        assert df > 20 and abs(stat - df) < 5.0 * np.sqrt(2.0 * df), (t, stat, df)
+    for i in range(0, n, 997):
+        net = int((types[i] == 1).sum()) - int((types[i] == 2).sum())
+        assert net == states[1, 1, i] - 1 and np.all(np.diff(times[i]) >= 0) and (len(times[i]) == 0 or times[i][-1] <= 30.0)
+    pf.close()
+
