@@ -295,7 +295,7 @@ def main():
             kernels[name] = k
         # The memory-bound stage of the path: normalise (k_wsum) + scan (k_offsets); the resampling gather of a full call
         # runs inside the next k_propagate.  The roofline object is quoted for k_offsets, the streaming kernel of that
-        # stage with the most bytes per launch, in both accountings; at this workload (16 MiB of state, 28 MiB working
+        # stage with the most algorithmic bytes per launch, in both accountings; at this workload (16 MiB of state, 36 MiB working
         # set) every streaming kernel is launch/latency-bound and served from L2 / Infinity Cache, so `frac` says little
         # about HBM: the fractions at working sets beyond the 256 MiB Infinity Cache are in profiles/ (hbm_scale_probe).
         mv = moved_bytes(P, S)
@@ -321,7 +321,7 @@ def main():
             "frac_moved_bytes": round(g.get("moved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
             "peak_measured": HBM_MEASURED_COPY_GBS,
             "frac_moved_bytes_of_peak_measured": round(g.get("moved_GBs", 0.0) / HBM_MEASURED_COPY_GBS, 4) if g else None,
-            "working_set_bytes": P * (2 * 4 * S + 8 + 4),
+            "working_set_bytes": P * (2 * 4 * S + 8 + 8 + 4),  # two state buffers, log-weights, fixed-point weights, boundaries
             "timing": f"HIP events stamped with each kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the "
                       f"launch stream), kernels of every {max(1, args.profile_every)}th timed step; the same quantity rocprofv3 reports per "
                       "dispatch (profiles/)",
