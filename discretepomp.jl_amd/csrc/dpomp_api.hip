@@ -905,7 +905,7 @@ const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>", 
                                             "dpomp::k_propagate_q<dpomp::RUser, 2>",  "dpomp::k_propagate_q<dpomp::RUser, 4>",
                                             "dpomp::k_propagate_c<dpomp::RUser, 16>"};
 const char* const kRtcOptions[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
-                                   "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                                   "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                                    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
 constexpr int kRtcOptionCount = (int)(sizeof kRtcOptions / sizeof kRtcOptions[0]);
 
