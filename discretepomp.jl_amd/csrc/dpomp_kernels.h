@@ -1487,14 +1487,20 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
         // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
         // dependency (N_{j-1} is recomputed from the exclusive cumulative weight).
-        int lo = (W == 0) ? ((i0 == 0) ? 0 : a.P) : (int)offspring_end(base + c[0] - w[0], W, a.P, r);
+        const int lo = (W == 0) ? ((i0 == 0) ? 0 : a.P) : (int)offspring_end(base + c[0] - w[0], W, a.P, r);
         int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
         const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
-#pragma unroll
-        for (int q = 0; q < kItems; ++q) {
-            const int hi = n[q];
-            for (int t = (lo + kParentBlock - 1) / kParentBlock; t * kParentBlock < hi; ++t) fp[t] = my_block;
-            lo = hi;
+        // the thread's particles own the slots [lo, n[3]): entries t with t * 256 in that range
+        const int t0 = (lo + kParentBlock - 1) / kParentBlock, t1 = (n[kItems - 1] + kParentBlock - 1) / kParentBlock;
+        const bool wide = t1 - t0 > 2;
+        if (!wide)
+            for (int t = t0; t < t1; ++t) fp[t] = my_block;
+        // Degenerate weights give one particle most of the offspring -- thousands of entries from one thread would
+        // take longer than the rest of the kernel: wide ranges are filled by the whole wave, 64 entries at a time.
+        for (unsigned long long todo = wave_ballot(wide); todo; todo &= todo - 1) {
+            const int src = __builtin_ctzll(todo);
+            const int w0 = __shfl(t0, src, 64), w1 = __shfl(t1, src, 64), wb = __shfl(my_block, src, 64);
+            for (int t = w0 + lane; t < w1; t += 64) fp[t] = wb;
         }
     } else {
         // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
