@@ -1486,8 +1486,17 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
         // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
         // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
-        // dependency (N_{j-1} is recomputed from the exclusive cumulative weight).
-        const int lo = (W == 0) ? ((i0 == 0) ? 0 : a.P) : (int)offspring_end(base + c[0] - w[0], W, a.P, r);
+        // dependency.  N_{j-1} of a thread's first particle is the last boundary of the thread before it: taken from
+        // the neighbouring lane, by the first lane of a wave from the wave before (through LDS), and computed from the
+        // tile's exclusive prefix by the first thread of the tile only -- not by every thread (a division each).
+        __shared__ int s_last[kBlock / 64];
+        int lo = __shfl_up(n[kItems - 1], 1, 64);
+        if (lane == 63) s_last[wid] = n[kItems - 1];
+        __syncthreads();
+        if (lane == 0) {
+            if (wid > 0) lo = s_last[wid - 1];
+            else lo = (W == 0) ? ((blk == 0) ? 0 : a.P) : (int)offspring_end(tile_prefix, W, a.P, r);
+        }
         int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
         const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
         // the thread's particles own the slots [lo, n[3]): entries t with t * 256 in that range
