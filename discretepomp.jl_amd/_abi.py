@@ -121,6 +121,8 @@ _PROTOTYPES = {
     "dpomp_get_null_bracket_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "dpomp_get_lane_utilisation": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "dpomp_last_event_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "dpomp_debug_alloc_count": (C.c_longlong, []),
+    "dpomp_static_max_bytes": (C.c_int64, []),
 }
 
 _lib = None
@@ -165,7 +167,12 @@ def load_library() -> C.CDLL:
             "There is no CPU fallback for the particle filter.")
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in _PROTOTYPES.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        try:
+            fn = getattr(lib, name)  # AttributeError if the library does not export it
+        except AttributeError:
+            if os.environ.get("DPOMP_HIP_LIB"):  # an experimental / older build loaded on purpose (tools/ab_probe.py)
+                continue
+            raise
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib

@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -30,20 +31,43 @@ namespace {
 
 thread_local std::string g_global_error;
 
-enum KernelId { KID_INIT = 0, KID_PROPAGATE, KID_WSUM, KID_SCAN_BLOCKS, KID_OFFSETS, KID_GATHER, KID_COPYSEG, KID_FILTER_SMALL, KID_COUNT };
+// Every allocating HIP call of the library goes through one of these, so that tests can assert that an entry point
+// which promises to allocate nothing (dpomp_pf_loglik_static) really does not: dpomp_debug_alloc_count().
+std::atomic<long long> g_alloc_calls{0};
+template <class T>
+hipError_t counted_malloc(T** ptr, size_t bytes) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc((void**)ptr, bytes);
+}
+template <class T>
+hipError_t counted_host_malloc(T** ptr, size_t bytes, unsigned flags) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipHostMalloc((void**)ptr, bytes, flags);
+}
+hipError_t counted_event_create(hipEvent_t* e) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipEventCreate(e);
+}
+hipError_t counted_stream_create(hipStream_t* s, unsigned flags) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    return hipStreamCreateWithFlags(s, flags);
+}
+
+enum KernelId { KID_INIT = 0, KID_PROPAGATE, KID_WSUM, KID_SCAN_BLOCKS, KID_OFFSETS, KID_GATHER, KID_COPYSEG, KID_FILTER_SMALL, KID_WEIGHTS_TILE, KID_COUNT };
 const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum",          "k_scan_blocks",
-                                             "k_offsets", "k_gather",    "k_copy_segments", "k_filter_small"};
+                                             "k_offsets", "k_gather",    "k_copy_segments", "k_filter_small",
+                                             "k_weights_tile"};
 
 typedef void (*PropFn)(PropArgs);
 
 constexpr int64_t kCompactionMinWaves = 4096;   // launches of at least this many waves run the compaction schedule
 constexpr int64_t kSmallFilterMaxWaves = 8192;  // calls of P <= 256 below this many waves run the whole-filter kernel
 constexpr int kDefaultPropVariant = 32;  // workgroup compaction, first live-lane count after 32 events
-// Automatic schedule, per observation interval.  A launch that fills the chip (>= 8192 waves: the issue slots a
+// Automatic schedule, per observation interval.  A launch that fills the chip (>= 4096 waves: the issue slots a
 // compaction frees are taken by other waves) runs with workgroup compaction unless, the last time this handle ran the
 // interval, a one-particle-per-lane schedule kept at least this fraction of the lanes busy (the kernels report that
 // figure whichever schedule they ran).  Measured on MI355X (tools/size_sweep.py): compaction wins by 1-4 % at
-// utilisations of 0.75-0.87 and by 20-30 % where epidemics die out early (0.3); below 8192 waves the static kernel
+// utilisations of 0.75-0.87 and by 20-30 % where epidemics die out early (0.3); below 4096 waves the static kernel
 // wins by 2-7 %.
 constexpr double kCompactionBelowUtil = 0.90;
 constexpr double kBoostChainFrac = 0.72;  // head start of the last workgroups: share of a wave's event chain (tools/ab_probe.py)
@@ -57,10 +81,12 @@ struct PropSet {
     PropFn fn1, q2, q4, c16, c32;
     SimFn sim;
     SmallFn small;
+    PropFn c32_flat;  // compaction kernel over filters laid end to end (small filters)
 };
-#define DPOMP_PROPSET(...)                                                                     \
-    {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>, \
-     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>, k_simulate_rec<__VA_ARGS__>, k_filter_small<__VA_ARGS__>}
+#define DPOMP_PROPSET(...)                                                                                \
+    {k_propagate<__VA_ARGS__>, k_propagate_q<__VA_ARGS__, 2>, k_propagate_q<__VA_ARGS__, 4>,            \
+     k_propagate_c<__VA_ARGS__, 16>, k_propagate_c<__VA_ARGS__, 32>, k_simulate_rec<__VA_ARGS__>,       \
+     k_filter_small<__VA_ARGS__>, k_propagate_c<__VA_ARGS__, 32, kModeFlat>}
 
 struct PropEntry {
     int builtin, S, E;
@@ -94,7 +120,7 @@ PropSet generic_set(int S, int E) {
     DPOMP_G(2, 2) DPOMP_G(2, 4) DPOMP_G(2, 8) DPOMP_G(4, 2) DPOMP_G(4, 4) DPOMP_G(4, 8) DPOMP_G(8, 2)
     DPOMP_G(8, 4) DPOMP_G(8, 8)
 #undef DPOMP_G
-    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return PropSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 struct KernelStat {
@@ -135,13 +161,13 @@ struct dpomp_handle {
     std::vector<double> obs_time;
     std::vector<int64_t> obs_id;
     std::vector<long long> ysum;
-    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
     // run-time compiled rate evaluator (dpomp_create_with_source)
     bool rtc = false;
     hipModule_t rtc_module = nullptr;
     hipFunction_t rtc_prop1 = nullptr, rtc_propc = nullptr, rtc_sim = nullptr, rtc_small = nullptr;
-    hipFunction_t rtc_q2 = nullptr, rtc_q4 = nullptr, rtc_c16 = nullptr;
+    hipFunction_t rtc_q2 = nullptr, rtc_q4 = nullptr, rtc_c16 = nullptr, rtc_c32_flat = nullptr;
     int evaluator = 0;  // DPOMP_EVALUATOR_*
     std::string jit_note;  // why a table model was not compiled (it then runs in the interpreter)
     // observation data on the device (k_filter_small loops over the observations inside the kernel)
@@ -169,6 +195,7 @@ struct dpomp_handle {
     std::vector<double> wave_chain; // [T] mean over waves of the longest event chain in the wave, last call (-1 = unknown)
     int resident_wgs = 2048;        // workgroups of the compaction kernel the device holds at once (8 per CU)
     bool no_head_start = false;     // DPOMP_HEAD_START=0: experiment switch
+    bool no_flat = false;           // DPOMP_FLAT=0: experiment switch (small filters one per workgroup column)
     double boost_frac = kBoostChainFrac;
     int boost_wgs = 0;              // 0 = half of resident_wgs
     std::string err;
@@ -243,7 +270,7 @@ struct DeviceScratch {
     }
     hipError_t doubles(double** out, size_t n) {
         void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, n * sizeof(double));
+        const hipError_t e = counted_malloc(&p, n * sizeof(double));
         if (e == hipSuccess) owned.push_back(p);
         *out = static_cast<double*>(p);
         return e;
@@ -253,7 +280,7 @@ struct DeviceScratch {
 hipEvent_t next_event(dpomp_handle* h) {
     if (h->events_used == h->event_pool.size()) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        if (counted_event_create(&e) != hipSuccess) return nullptr;
         h->event_pool.push_back(e);
     }
     return h->event_pool[h->events_used++];
@@ -422,7 +449,7 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     const size_t n_state = (size_t)B * p->S * p->Pp;
 #define DPOMP_ALLOC(ptr, bytes)                                                    \
     do {                                                                           \
-        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                        \
+        hipError_t e_ = counted_malloc((void**)&(ptr), (bytes));                        \
         if (e_ != hipSuccess) {                                                    \
             pop_release(p);                                                        \
             return fail(h, DPOMP_ENOMEM, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
@@ -443,8 +470,8 @@ int pop_alloc_impl(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out) {
     DPOMP_ALLOC(p->theta, (size_t)B * p->K * 8);
     DPOMP_ALLOC(p->ancestors, (size_t)B * 8);
 #undef DPOMP_ALLOC
-    if (hipHostMalloc((void**)&p->h_result, p->ctl_result_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc((void**)&p->h_theta, (size_t)B * p->K * 8, hipHostMallocDefault) != hipSuccess) {
+    if (counted_host_malloc((void**)&p->h_result, p->ctl_result_bytes, hipHostMallocDefault) != hipSuccess ||
+        counted_host_malloc((void**)&p->h_theta, (size_t)B * p->K * 8, hipHostMallocDefault) != hipSuccess) {
         pop_release(p);
         return fail(h, DPOMP_ENOMEM, "hipHostMalloc of the staging buffers failed");
     }
@@ -501,7 +528,7 @@ int pop_ensure_pos(dpomp_handle* h, dpomp_pop* p) {
     if (p->posw) return DPOMP_OK;
     if (p->static_mem) return fail(h, DPOMP_ESTATE, "static population was carved without the stratified/multinomial buffers");
     double *a = nullptr, *b = nullptr;
-    if (hipMalloc((void**)&a, (size_t)p->B * p->Pp * 8) != hipSuccess || hipMalloc((void**)&b, (size_t)p->B * p->nblk * 8) != hipSuccess) {
+    if (counted_malloc((void**)&a, (size_t)p->B * p->Pp * 8) != hipSuccess || counted_malloc((void**)&b, (size_t)p->B * p->nblk * 8) != hipSuccess) {
         (void)hipFree(a);
         (void)hipFree(b);
         return fail(h, DPOMP_ENOMEM, "hipMalloc of the scaled cumulative weights failed");
@@ -517,7 +544,7 @@ int pop_ensure_adaptive(dpomp_handle* h, dpomp_pop* p) {
     const size_t B = (size_t)p->B;
     const size_t bytes[6] = {B * p->nblk * 16, B * 4, B * 4, B * 8, B * 8, B * 4};
     for (int i = 0; i < 6; ++i)
-        if (hipMalloc(&q[i], bytes[i]) != hipSuccess) {
+        if (counted_malloc(&q[i], bytes[i]) != hipSuccess) {
             for (int j = 0; j < 6; ++j) (void)hipFree(q[j]);
             return fail(h, DPOMP_ENOMEM, "hipMalloc of the ESS-adaptive buffers failed");
         }
@@ -539,7 +566,7 @@ hipError_t clear_device(hipStream_t st, void* ptr, size_t bytes) {
     return hipGetLastError();
 }
 
-hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a);
+hipError_t launch_propagate(dpomp_handle* h, int variant, int mode, dim3 grid, dim3 block, hipStream_t st, PropArgs& a);
 
 // End of a filter call: the first `bytes` of the control block onto the host (asynchronous copy into the pinned staging
 // buffer, one synchronisation).  Tried instead and not kept: a last kernel that stores the results straight into the
@@ -650,10 +677,15 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     // the plain kernel by 5-9 % from 2^18 particles on, tools/size_probe.py) unless the interval kept the lanes busy last
     // time; below that the plain kernel wins (the issue slots a compaction frees have no other wave to go to).
     // lane_util = -1 (not measured yet) -> compaction.
+    // (force_rpl 33 = the compaction schedule with the end-to-end layout of small filters forced on: tests, experiments)
     auto pick_variant = [&](int k) {
-        if (h->force_rpl) return h->force_rpl;
+        if (h->force_rpl) return h->force_rpl == 33 ? 32 : h->force_rpl;
         return (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
     };
+    // Filters of a few hundred particles are laid end to end over the workgroups of the compaction kernel (kModeFlat):
+    // one filter per workgroup column leaves the last wave of every 200-particle filter with 8 of 64 lanes.
+    const bool use_flat = p->P <= kFlatMaxP && B * p->P < ((int64_t)1 << 31) &&
+                          (h->force_rpl == 33 || (h->force_rpl == 0 && !h->no_flat && p->P % kBlock != 0));
     // A systematic resampling that is followed by another propagation in this call is not carried out by a gather pass:
     // the next propagation reads every slot's state from its ancestor (PropArgs::parents) and writes to the other buffer.
     bool pending_gather = false;
@@ -696,15 +728,17 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
         a.yval = h->d_obs_val + (size_t)k * h->n_obs_values;
         a.n_yval = h->n_obs_values;
         a.sched = reinterpret_cast<unsigned long long*>(p->ctl + p->sched_offset) + kSchedStride * (size_t)k;
+        a.B = (int32_t)B;
         {
             const int rpl = pick_variant(k);
+            const int mode = (rpl == 32 && use_flat) ? kModeFlat : kModeBlock;
             const int64_t chunk = (int64_t)kBlock * ((rpl == 2 || rpl == 4) ? rpl : 1);
             // Head start of the compaction kernel: the last half round of workgroups, for kBoostChainFrac of the event
             // chain a wave had in this interval at the previous call (none before anything has been measured).
             a.boost_events = 0;
             a.boost_from = 0;
+            const int64_t n_wg = mode == kModeFlat ? (B * p->P + kBlock - 1) / kBlock : (p->P + kBlock - 1) / kBlock * B;
             if ((rpl == 16 || rpl == 32) && h->wave_chain[k] > 0.0 && !h->no_head_start) {
-                const int64_t n_wg = (p->P + kBlock - 1) / kBlock * B;
                 a.boost_from = (int32_t)std::max<int64_t>(0, n_wg - (h->boost_wgs ? h->boost_wgs : h->resident_wgs / 2));
                 a.boost_events = (int32_t)std::min(1.0e9, std::max(1.0, h->boost_frac * h->wave_chain[k]));
             }
@@ -712,7 +746,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             {
                 static unsigned long long* tr_buf = nullptr;
                 const size_t per = (size_t)((p->P + kBlock - 1) / kBlock) * B * 8;
-                if (!tr_buf) hipMalloc((void**)&tr_buf, per * 8 * 64);
+                if (!tr_buf) counted_malloc((void**)&tr_buf, per * 8 * 64);
                 a.trace = (k < 64) ? tr_buf + per * k : nullptr;
                 h->trace_buf = tr_buf;
                 h->trace_per = per;
@@ -720,7 +754,8 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             }
 #endif
             // iterate_particles! :56
-            HIPCHK(h, launch_propagate(h, rpl, dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B), block, st, a));
+            const dim3 grid = mode == kModeFlat ? dim3((unsigned)n_wg, 1u) : dim3((unsigned)((p->P + chunk - 1) / chunk), (unsigned)B);
+            HIPCHK(h, launch_propagate(h, rpl, mode, grid, block, st, a));
             if (pending_gather) {
                 p->cur ^= 1;
                 pending_gather = false;
@@ -762,17 +797,18 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.obs_k = (uint32_t)k;
             w.seg_base = (uint32_t)seg_base;
             w.seed = seed;
-            {
-                timed_launch(h, KID_WSUM, k_wsum, grid_tiles, block, 0, st, w);
-            }
             const bool resample = obs_i < T;  // :62  (the ESS criterion is commented out in the reference, :63-68)
+            // a filter of at most one tile: weights, their sum, the :60 update and the offspring boundaries in ONE launch
+            const bool one_tile = p->nblk == 1 && !adaptive && h->rs_type == DPOMP_RS_SYSTEMATIC;
+            if (one_tile) timed_launch(h, KID_WEIGHTS_TILE, k_weights_tile, dim3((unsigned)B), block, 0, st, w, resample ? 1 : 0);
+            else timed_launch(h, KID_WSUM, k_wsum, grid_tiles, block, 0, st, w);
             const bool fused = resample && p->nblk <= kFusedScanMaxTiles;
-            if (!fused) {
+            if (!fused && !one_tile) {
                 // output += log(cum_weight[end]/P)  :60
                 timed_launch(h, KID_SCAN_BLOCKS, k_scan_blocks, dim3((unsigned)B), block, 0, st, w);
             }
             if (resample) {
-                {
+                if (!one_tile) {
                     // fused: also the tile-sum scan and the :60 update
                     if (fused) timed_launch(h, KID_OFFSETS, k_offsets<true>, grid_tiles, block, 0, st, w);
                     else timed_launch(h, KID_OFFSETS, k_offsets<false>, grid_tiles, block, 0, st, w);
@@ -899,11 +935,12 @@ RtcApi* rtc_api() {  // loaded on first use only: the library itself does not de
     return &api;
 }
 
-constexpr int kRtcKernels = 7;
+constexpr int kRtcKernels = 8;
 const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>",       "dpomp::k_propagate_c<dpomp::RUser, 32>",
                                             "dpomp::k_simulate_rec<dpomp::RUser>",    "dpomp::k_filter_small<dpomp::RUser>",
                                             "dpomp::k_propagate_q<dpomp::RUser, 2>",  "dpomp::k_propagate_q<dpomp::RUser, 4>",
-                                            "dpomp::k_propagate_c<dpomp::RUser, 16>"};
+                                            "dpomp::k_propagate_c<dpomp::RUser, 16>",
+                                            "dpomp::k_propagate_c<dpomp::RUser, 32, dpomp::kModeFlat>"};
 const char* const kRtcOptions[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
                                    "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                                    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
@@ -955,7 +992,7 @@ bool cache_file_read(const std::string& file, RtcBinary& out) {
     bool ok = false;
     char magic[8];
     uint32_t n = 0;
-    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT2", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT3", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
         ok = true;
         for (int i = 0; ok && i < kRtcKernels; ++i) {
             uint32_t len = 0;
@@ -984,7 +1021,7 @@ void cache_file_write(const std::string& dir, const std::string& file, const Rtc
     FILE* f = fopen(tmpname.c_str(), "wb");
     if (!f) return;
     const uint32_t n = kRtcKernels;
-    bool ok = fwrite("DPOMPRT2", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
+    bool ok = fwrite("DPOMPRT3", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
     for (int i = 0; ok && i < kRtcKernels; ++i) {
         const uint32_t len = (uint32_t)b.lowered[i].size();
         ok = fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[i].data(), 1, len, f) == len;
@@ -1087,7 +1124,8 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
 // Loads a compiled model into the handle (module + the seven kernels).
 int rtc_load(dpomp_handle* h, const RtcBinary& bin, std::string& why) {
     hipError_t me = hipModuleLoadData(&h->rtc_module, bin.code.data());
-    hipFunction_t* fns[kRtcKernels] = {&h->rtc_prop1, &h->rtc_propc, &h->rtc_sim, &h->rtc_small, &h->rtc_q2, &h->rtc_q4, &h->rtc_c16};
+    hipFunction_t* fns[kRtcKernels] = {&h->rtc_prop1, &h->rtc_propc, &h->rtc_sim, &h->rtc_small, &h->rtc_q2, &h->rtc_q4, &h->rtc_c16,
+                                       &h->rtc_c32_flat};
     for (int i = 0; me == hipSuccess && i < kRtcKernels; ++i) me = hipModuleGetFunction(fns[i], h->rtc_module, bin.lowered[i].c_str());
     if (me != hipSuccess) {
         why = hipGetErrorString(me);
@@ -1136,13 +1174,16 @@ bool generic_jit_enabled() {
 }
 
 // One launch site for the propagation kernel: compiled-in template instance or run-time compiled module function.
-hipError_t launch_propagate(dpomp_handle* h, int variant, dim3 grid, dim3 block, hipStream_t st, PropArgs& a) {
+// (mode: kModeBlock / kModeFlat of the compaction kernel, variant 32 only)
+hipError_t launch_propagate(dpomp_handle* h, int variant, int mode, dim3 grid, dim3 block, hipStream_t st, PropArgs& a) {
     if (h->rtc) {
         void* params[] = {&a};
         hipFunction_t f = variant == 4 ? h->rtc_q4 : variant == 2 ? h->rtc_q2 : variant == 16 ? h->rtc_c16 : variant == 32 ? h->rtc_propc : h->rtc_prop1;
+        if (variant == 32 && mode == kModeFlat) f = h->rtc_c32_flat;
         return timed_module_launch(h, KID_PROPAGATE, f, grid, block, st, params);
     }
     PropFn fn = variant == 4 ? h->prop.q4 : variant == 2 ? h->prop.q2 : variant == 16 ? h->prop.c16 : variant == 32 ? h->prop.c32 : h->prop.fn1;
+    if (variant == 32 && mode == kModeFlat) fn = h->prop.c32_flat;
     timed_launch(h, KID_PROPAGATE, fn, grid, block, 0, st, a);
     return hipGetLastError();
 }
@@ -1209,7 +1250,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     dpomp_handle* h = new dpomp_handle;
     h->device = device;
     e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = counted_stream_create(&h->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         rc = fail(nullptr, DPOMP_EDEVICE, "hipStreamCreate: %s", hipGetErrorString(e));
         delete h;
@@ -1247,8 +1288,8 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     }
     {   // pinned staging of dpomp_pf_loglik_static, sized for its largest call
         const size_t n_res = (size_t)DPOMP_STATIC_MAX_SEGMENTS * 12 + 16 + (size_t)d->n_obs * kSchedStride * 8 + 64;
-        if (hipHostMalloc((void**)&h->static_h_result, n_res, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void**)&h->static_h_theta, (size_t)DPOMP_STATIC_MAX_SEGMENTS * DPOMP_MAX_PARAMS * 8, hipHostMallocDefault) != hipSuccess) {
+        if (counted_host_malloc((void**)&h->static_h_result, n_res, hipHostMallocDefault) != hipSuccess ||
+            counted_host_malloc((void**)&h->static_h_theta, (size_t)DPOMP_STATIC_MAX_SEGMENTS * DPOMP_MAX_PARAMS * 8, hipHostMallocDefault) != hipSuccess) {
             rc = fail(nullptr, DPOMP_ENOMEM, "hipHostMalloc of the static staging buffers failed");
             dpomp_destroy(h);
             return rc;
@@ -1318,12 +1359,13 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         }
     }
     if (const char* env = getenv("DPOMP_RPL")) h->force_rpl = atoi(env);
+    if (const char* env = getenv("DPOMP_FLAT")) h->no_flat = atoi(env) == 0;
     {
         std::vector<int32_t> oid(d->n_obs);
         for (int t = 0; t < d->n_obs; ++t) oid[t] = d->obs_id[t] > 0 ? 1 : 0;
-        hipError_t oe = hipMalloc((void**)&h->d_obs_time, (size_t)d->n_obs * 8);
-        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_ysum, (size_t)d->n_obs * 8);
-        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_obs_id, (size_t)d->n_obs * 4);
+        hipError_t oe = counted_malloc((void**)&h->d_obs_time, (size_t)d->n_obs * 8);
+        if (oe == hipSuccess) oe = counted_malloc((void**)&h->d_ysum, (size_t)d->n_obs * 8);
+        if (oe == hipSuccess) oe = counted_malloc((void**)&h->d_obs_id, (size_t)d->n_obs * 4);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_time, h->obs_time.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_ysum, h->ysum.data(), (size_t)d->n_obs * 8, hipMemcpyHostToDevice);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_id, oid.data(), (size_t)d->n_obs * 4, hipMemcpyHostToDevice);
@@ -1331,7 +1373,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         const size_t nval = (size_t)d->n_obs * (d->n_obs_values > 0 ? d->n_obs_values : 1);
         std::vector<long long> vals(nval, 0);
         for (size_t i = 0; i < (size_t)d->n_obs * d->n_obs_values; ++i) vals[i] = d->obs_value[i];
-        if (oe == hipSuccess) oe = hipMalloc((void**)&h->d_obs_val, nval * 8);
+        if (oe == hipSuccess) oe = counted_malloc((void**)&h->d_obs_val, nval * 8);
         if (oe == hipSuccess) oe = hipMemcpy(h->d_obs_val, vals.data(), nval * 8, hipMemcpyHostToDevice);
         if (oe != hipSuccess) {
             rc = fail(nullptr, DPOMP_EDEVICE, "uploading the observation data: %s", hipGetErrorString(oe));
@@ -1387,8 +1429,8 @@ int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac) {
 
 int dpomp_set_propagate_variant(dpomp_handle* h, int rpl) {
     if (!h) return DPOMP_EINVAL;
-    if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4 && rpl != 16 && rpl != 32)
-        return fail(h, DPOMP_EINVAL, "propagate variant must be 0, 1, 2, 4, 16 or 32");
+    if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4 && rpl != 16 && rpl != 32 && rpl != 33)
+        return fail(h, DPOMP_EINVAL, "propagate variant must be 0, 1, 2, 4, 16, 32 or 33");
     h->force_rpl = rpl;
     return DPOMP_OK;
 }
@@ -1557,7 +1599,7 @@ int dpomp_simulate(dpomp_handle* h, const double* theta, int64_t B, int64_t P, u
     if (rc != DPOMP_OK) return rc;
     int32_t* rec = nullptr;
     const size_t n = (size_t)h->T * B * p->S * p->Pp;
-    if (hipMalloc((void**)&rec, n * 4) != hipSuccess) {
+    if (counted_malloc((void**)&rec, n * 4) != hipSuccess) {
         pop_release(p);
         return fail(h, DPOMP_ENOMEM, "hipMalloc(%zu) for the simulation record", n * 4);
     }
@@ -1592,12 +1634,12 @@ int dpomp_simulate_events(dpomp_handle* h, const double* theta, int64_t P, uint6
     long long *d_counts = nullptr, *d_states = nullptr;
     int32_t* d_type = nullptr;
     const size_t nev = (size_t)P * max_events;
-    hipError_t e = hipMalloc((void**)&d_theta, (size_t)K * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_obs, (size_t)T * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_counts, (size_t)P * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_states, (size_t)T * S * P * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_time, nev * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_type, nev * 4);
+    hipError_t e = counted_malloc((void**)&d_theta, (size_t)K * 8);
+    if (e == hipSuccess) e = counted_malloc((void**)&d_obs, (size_t)T * 8);
+    if (e == hipSuccess) e = counted_malloc((void**)&d_counts, (size_t)P * 8);
+    if (e == hipSuccess) e = counted_malloc((void**)&d_states, (size_t)T * S * P * 8);
+    if (e == hipSuccess) e = counted_malloc((void**)&d_time, nev * 8);
+    if (e == hipSuccess) e = counted_malloc((void**)&d_type, nev * 4);
     int rc = DPOMP_OK;
     if (e != hipSuccess) {
         rc = fail(h, DPOMP_ENOMEM, "hipMalloc for the event record: %s", hipGetErrorString(e));
@@ -1707,9 +1749,9 @@ int dpomp_set_profiling(dpomp_handle* h, int on) {
         std::vector<float> v;
         const int n = 64;
         std::vector<hipEvent_t> ev(2 * n);
-        for (auto& e : ev) HIPCHK(h, hipEventCreate(&e));
+        for (auto& e : ev) HIPCHK(h, counted_event_create(&e));
         int32_t* scratch = nullptr;
-        HIPCHK(h, hipMalloc((void**)&scratch, (size_t)kTile * 64 * 4));
+        HIPCHK(h, counted_malloc((void**)&scratch, (size_t)kTile * 64 * 4));
         for (int i = 0; i < n; ++i) {
             // filler: S rows of 8 tiles each (S <= 8 -> at most 64 tiles = the scratch size), 16-B aligned rows
             hipLaunchKernelGGL(k_init, dim3(8, 1), dim3(kBlock), 0, h->stream, h->dm, scratch, (int64_t)kTile * 8);
@@ -1758,6 +1800,10 @@ int dpomp_get_lane_utilisation(dpomp_handle* h, int obs_index, double* util) {
     *util = h->lane_util[(size_t)obs_index - 1];
     return DPOMP_OK;
 }
+
+int64_t dpomp_static_max_bytes(void) { return (int64_t)kStaticScratchBytes; }
+
+long long dpomp_debug_alloc_count(void) { return g_alloc_calls.load(std::memory_order_relaxed); }
 
 int dpomp_last_event_count(dpomp_handle* h, uint64_t* events) {
     if (!h || !events) return DPOMP_EINVAL;

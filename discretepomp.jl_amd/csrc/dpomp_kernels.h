@@ -83,6 +83,7 @@ struct PropArgs {
     // dispatched last -- run at raised wave priority until their particles have executed `boost_events` events
     // (0 = no head start).  Scheduling only: results do not depend on it.
     int32_t boost_from, boost_events;
+    int32_t B;  // filters of the launch (kModeFlat lays them end to end)
 #ifdef DPOMP_TRACE_WG
     unsigned long long* trace;    // [workgroups][8] timeline of every workgroup (experimental builds: tools/wg_timeline.py)
 #endif
@@ -757,6 +758,41 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
     }
 }
 
+// MODE of k_propagate_c: which particles the 256 slots of a workgroup hold.
+//   kModeBlock  slots blockIdx.x * 256 .. of filter blockIdx.y (filters of many particles);
+//   kModeFlat   the filters of a call laid end to end: flat index f = blockIdx.x * 256 + slot, filter f / P, particle
+//               f % P -- filters of a few hundred particles (the reference's default is 200, C_DF_PF_P) then fill every
+//               lane of every workgroup instead of leaving the last wave of each filter mostly empty.  A workgroup
+//               then holds particles of several filters: the parameter vector is per lane (re-read when a compaction
+//               moves a context into the lane) and the per-filter reductions of the epilogue are segmented.
+enum : int { kModeBlock = 0, kModeFlat = 1 };
+constexpr int kFlatMaxP = 512;  // kModeFlat: particles per filter (ancestor windows of 256/P + 2 filters fit the stage)
+
+// number of set bits of a wave mask below the calling lane
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// kModeFlat ancestor search: the workgroup's slots span the filters b_lo..b_hi; their offspring boundaries (P each) are
+// staged in LDS and every lane searches its own filter's segment (first j with N_j > p, as find_ancestor).  All
+// threads must call (barriers).
+__device__ __forceinline__ int find_ancestor_flat(const PropArgs& a, int b, int p, bool valid, int32_t* stage) {
+    const uint32_t f0 = blockIdx.x * kBlock, total = (uint32_t)a.B * (uint32_t)a.P;
+    const int b_lo = (int)(f0 / (uint32_t)a.P);
+    const int b_hi = (int)((min(f0 + kBlock, total) - 1u) / (uint32_t)a.P);
+    const int M = (b_hi - b_lo + 1) * a.P;  // <= 255 + 2 P <= kStageSlots
+    for (int t = threadIdx.x; t < M; t += kBlock) {
+        const int fb = t / a.P;
+        stage[t] = a.offs[(int64_t)(b_lo + fb) * a.Pp + (t - fb * a.P)];
+    }
+    __syncthreads();
+    int j = 0;
+    if (valid) j = first_greater(stage + (b - b_lo) * a.P, a.P, p);
+    __syncthreads();  // the staging area is reused by the caller
+    if (valid && a.noresample && a.noresample[b]) j = p;
+    return valid ? min(j, a.P - 1) : 0;
+}
+
 // ---- k_propagate_c: one particle per lane + workgroup-level compaction ------------------------------
 // Lanes whose particle has reached t_max idle until the slowest lane of the wave is done, and a
 // wave with 5 live lanes costs the VALU as much as one with 64.  Every CHK events the workgroup
@@ -766,9 +802,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
 // meeting the barrier.  Finished particles park their final state in an LDS tile, and the
 // epilogue (weights, coalesced write-back, reductions) runs at full occupancy.  The arithmetic of
 // a particle does not depend on the lane it runs in, so results stay bit-identical.
-template <class R, int CHK>
+template <class R, int CHK, int MODE = kModeBlock>
 __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 waves per SIMD: at most 64 VGPRs
     constexpr int S = R::S, E = R::E;
+    constexpr bool kFlat = MODE == kModeFlat;
     using TW = typename cond_t<(S <= 4), uint32_t, uint64_t>::type;
     __shared__ double s_log[kLogTableSize][2];
     __shared__ int32_t s_res[S][kBlock];  // final state by particle slot
@@ -794,14 +831,27 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     const unsigned long long tr_t0 = wall_clock64();
     unsigned long long tr_t1 = 0, tr_x1 = 0, tr_x2 = 0, tr_x3 = 0;  // loop start; when the 2nd / 3rd / 4th wave emptied
 #endif
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool valid = p < a.P;
+    // (filter, particle) of the particle that STARTS in local slot `slot`; false past the end
+    auto locate = [&](int slot, int& fb, int& fp) -> bool {
+        if constexpr (kFlat) {
+            const uint32_t f = blockIdx.x * kBlock + (uint32_t)slot;
+            const bool ok = f < (uint32_t)a.B * (uint32_t)a.P;
+            fb = ok ? (int)(f / (uint32_t)a.P) : 0;
+            fp = ok ? (int)(f - (uint32_t)fb * (uint32_t)a.P) : 0;
+            return ok;
+        } else {
+            fb = blockIdx.y;
+            fp = blockIdx.x * kBlock + slot;
+            return fp < a.P;
+        }
+    };
+    int b, p;
+    const bool valid = locate(threadIdx.x, b, p);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int s_real = R::kGeneric ? a.m.S : S;
     int32_t* st = a.state + (int64_t)b * s_real * a.Pp;
     const double* th = a.theta + (int64_t)b * a.m.K;
-    const ThetaRegs<R> th_regs(th, a.m.K);
+    typename cond_t<kFlat, ThetaRegs<R>, const ThetaRegs<R>>::type th_regs(th, a.m.K);
     const double* thr = th_regs.get(th);  // for the rate evaluator inside the event loop
 
     for (int i = threadIdx.x; i < 2 * kLogTableSize; i += kBlock) (&s_log[0][0])[i] = (&kLogTable[0][0])[i];
@@ -810,7 +860,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     int pj = p;
     if (a.parents) {         // resampling fused into the load (the compaction buffer is free until the first compaction)
         ld = a.parents + (int64_t)b * s_real * a.Pp;
-        pj = find_ancestor(a, b, p, valid, reinterpret_cast<int32_t*>(c_raw));
+        pj = kFlat ? find_ancestor_flat(a, b, p, valid, reinterpret_cast<int32_t*>(c_raw))
+                   : find_ancestor(a, b, p, valid, reinterpret_cast<int32_t*>(c_raw));
     }
 
     int x[S];
@@ -824,7 +875,9 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     const LogRegs lr = log_regs();  // (a polynomial constant of the logarithm, in a VGPR pair for the whole kernel)
     const int cap = a.m.cap;
     int cur = threadIdx.x;
-    const int n_start = min(kBlock, a.P - (int)blockIdx.x * kBlock);  // particles this workgroup starts with
+    // particles this workgroup starts with
+    const int n_start = kFlat ? (int)min((uint32_t)kBlock, (uint32_t)a.B * (uint32_t)a.P - blockIdx.x * kBlock)
+                              : min(kBlock, a.P - (int)blockIdx.x * kBlock);
     // Events until the next count of live lanes (workgroup-uniform).  A count is a barrier for four waves, and it can
     // only pay once particles have finished: CHK events at first, twice that while every particle of the workgroup still
     // runs, 3/8 CHK once they have started to finish (the finer the packing, the fewer lanes idle in a live wave; below
@@ -944,15 +997,24 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
                 time = moved_time;
                 ahead = moved_ahead;
                 cur = moved_nc.y;
+                if constexpr (kFlat) {  // the parameters of the filter the moved-in particle belongs to
+                    int mb, mp;
+                    locate(cur, mb, mp);
+                    th = a.theta + (int64_t)mb * a.m.K;
+                    th_regs = ThetaRegs<R>(th, a.m.K);
+                    thr = th_regs.get(th);
+                }
             }
         }
     }
     __syncthreads();
 
+    // thread t closes the particle that STARTED in slot t
     double g = -__builtin_inf();
     unsigned long long ev = 0;
     capped = false;
     if (valid) {
+        if constexpr (kFlat) th = a.theta + (int64_t)b * a.m.K;  // (the lane may have run particles of other filters)
         int xv[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -969,10 +1031,26 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
             a.logw[(int64_t)b * a.Pp + p] = g;
         }
     }
-    const double wm = wave_max(g);
+    double wm = -__builtin_inf();
+    int wcap = 0;
+    if constexpr (kFlat) {
+        // the particles of a wave belong to several filters: one maximum per filter present (ballot loop), flags per lane
+        if (capped) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+        unsigned long long todo = wave_ballot(a.want_weight && g > -__builtin_inf());
+        while (todo) {  // (wave-uniform)
+            const int leader = (int)__builtin_ctzll(todo);
+            const int bb = __builtin_amdgcn_readlane(b, leader);
+            const bool same = b == bb;
+            const double m = wave_max(same ? g : -__builtin_inf());
+            if (lane == leader) publish_max(&a.segmax[bb], ordered_key(m));
+            todo &= ~wave_ballot(same);
+        }
+    } else {
+        wm = wave_max(g);
+        wcap = wave_any(capped);
+    }
     const unsigned long long wev = wave_sum(ev);
     const int wnmax = wave_max_i32((int)ev);  // particle slots in launch order: the static schedule's waves
-    const int wcap = wave_any(capped);
     if (lane == 0) {
         s_max[wid] = wm;
         s_ev[wid] = wev;
@@ -991,8 +1069,8 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
             bs += (unsigned long long)s_wcnt[0][w];
             bc |= s_cap[w];
         }
-        if (a.want_weight && bm > -__builtin_inf()) publish_max(&a.segmax[b], ordered_key(bm));
-        if (bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
+        if (!kFlat && a.want_weight && bm > -__builtin_inf()) publish_max(&a.segmax[b], ordered_key(bm));
+        if (!kFlat && bc) atomicOr(&a.status[b], 1u /* DPOMP_ST_EVENT_CAP */);
         if (be) {  // events of this interval, and what a one-particle-per-lane schedule makes of it (dpomp_get_lane_utilisation)
             sched_add(a.sched, be, 64ull * bs);
         }
@@ -1411,6 +1489,48 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
     }
 }
 
+// Systematic resampling of one tile: offspring boundaries N_j of the tile's particles from their inclusive cumulative
+// weights base + c[q], and the first_parent map entries they own.  Called by every thread of the workgroup (barrier).
+__device__ __forceinline__ void systematic_boundaries(const WeightArgs& a, int b, int blk, unsigned long long tile_prefix,
+                                                      unsigned long long base, const unsigned long long (&c)[kItems],
+                                                      unsigned long long W, double r) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    int n[kItems];
+#pragma unroll
+    for (int q = 0; q < kItems; ++q)
+        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
+    *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
+    // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
+    // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
+    // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
+    // dependency.  N_{j-1} of a thread's first particle is the last boundary of the thread before it: taken from
+    // the neighbouring lane, by the first lane of a wave from the wave before (through LDS), and computed from the
+    // tile's exclusive prefix by the first thread of the tile only -- not by every thread (a division each).
+    __shared__ int s_last[kBlock / 64];
+    int lo = __shfl_up(n[kItems - 1], 1, 64);
+    if (lane == 63) s_last[wid] = n[kItems - 1];
+    __syncthreads();
+    if (lane == 0) {
+        if (wid > 0) lo = s_last[wid - 1];
+        else lo = (W == 0) ? ((blk == 0) ? 0 : a.P) : (int)offspring_end(tile_prefix, W, a.P, r);
+    }
+    int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
+    const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
+    // the thread's particles own the slots [lo, n[3]): entries t with t * 256 in that range
+    const int t0 = (lo + kParentBlock - 1) / kParentBlock, t1 = (n[kItems - 1] + kParentBlock - 1) / kParentBlock;
+    const bool wide = t1 - t0 > 2;
+    if (!wide)
+        for (int t = t0; t < t1; ++t) fp[t] = my_block;
+    // Degenerate weights give one particle most of the offspring -- thousands of entries from one thread would
+    // take longer than the rest of the kernel: wide ranges are filled by the whole wave, 64 entries at a time.
+    for (unsigned long long todo = wave_ballot(wide); todo; todo &= todo - 1) {
+        const int src = __builtin_ctzll(todo);
+        const int w0 = __shfl(t0, src, 64), w1 = __shfl(t1, src, 64), wb = __shfl(my_block, src, 64);
+        for (int t = w0 + lane; t < w1; t += 64) fp[t] = wb;
+    }
+}
+
 // k_offsets<FUSED>: inclusive fixed-point cumulative weight c_j of every particle (tile scan + tile
 // prefix) -> offspring boundary N_j.  Slots [N_{j-1}, N_j) of the resampled population copy
 // particle j: rsp_systematic's u_i = (u1 + (i-1)/P) cw[end], `while u[i] > cw[j]`
@@ -1478,39 +1598,7 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     const double r = a.rsu[b];  // rand() of hmm_pf_resample.jl:27 (drawn in k_wsum)
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
     if (a.rs_type == 1) {
-        int n[kItems];
-#pragma unroll
-        for (int q = 0; q < kItems; ++q)
-            n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
-        *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
-        // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
-        // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
-        // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
-        // dependency.  N_{j-1} of a thread's first particle is the last boundary of the thread before it: taken from
-        // the neighbouring lane, by the first lane of a wave from the wave before (through LDS), and computed from the
-        // tile's exclusive prefix by the first thread of the tile only -- not by every thread (a division each).
-        __shared__ int s_last[kBlock / 64];
-        int lo = __shfl_up(n[kItems - 1], 1, 64);
-        if (lane == 63) s_last[wid] = n[kItems - 1];
-        __syncthreads();
-        if (lane == 0) {
-            if (wid > 0) lo = s_last[wid - 1];
-            else lo = (W == 0) ? ((blk == 0) ? 0 : a.P) : (int)offspring_end(tile_prefix, W, a.P, r);
-        }
-        int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
-        const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
-        // the thread's particles own the slots [lo, n[3]): entries t with t * 256 in that range
-        const int t0 = (lo + kParentBlock - 1) / kParentBlock, t1 = (n[kItems - 1] + kParentBlock - 1) / kParentBlock;
-        const bool wide = t1 - t0 > 2;
-        if (!wide)
-            for (int t = t0; t < t1; ++t) fp[t] = my_block;
-        // Degenerate weights give one particle most of the offspring -- thousands of entries from one thread would
-        // take longer than the rest of the kernel: wide ranges are filled by the whole wave, 64 entries at a time.
-        for (unsigned long long todo = wave_ballot(wide); todo; todo &= todo - 1) {
-            const int src = __builtin_ctzll(todo);
-            const int w0 = __shfl(t0, src, 64), w1 = __shfl(t1, src, 64), wb = __shfl(my_block, src, 64);
-            for (int t = w0 + lane; t < w1; t += 64) fp[t] = wb;
-        }
+        systematic_boundaries(a, b, blk, tile_prefix, base, c, W, r);
     } else {
         // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
         // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
@@ -1524,6 +1612,47 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         *reinterpret_cast<double2*>(dst + 2) = make_double2(ps[2], ps[3]);
         if (threadIdx.x == kBlock - 1) a.tile_end_pos[(int64_t)b * a.nblk + blk] = ps[kItems - 1];
     }
+}
+
+// ---- k_weights_tile: k_wsum + k_offsets<true> in one launch for filters of at most one tile (P <= 1024) -------
+// With a single tile per filter nothing crosses a workgroup: the tile's sum IS the filter's total, so the fixed-point
+// weights, their sum, the log mean weight (hmm_particle_filter.jl:60) and the offspring boundaries of rsp_systematic
+// (hmm_pf_resample.jl:24-42) come from one workgroup per filter -- one launch per observation instead of two, and the
+// weights never go through memory.  Same arithmetic, operation for operation, as the two-kernel path (integer sums are
+// order-free).  Systematic resampling, non-adaptive mode.
+__global__ __launch_bounds__(kBlock) void k_weights_tile(WeightArgs a, int resample) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ unsigned long long s_w[kBlock / 64];
+    __shared__ double s_r;
+    const double m = ordered_value(a.segmax[b]);
+    const int64_t i0 = threadIdx.x * kItems;
+    unsigned long long c[kItems] = {0ull, 0ull, 0ull, 0ull};
+    if (i0 < a.P) {  // (threads past the filter hold zero weights: no load)
+        const double* src = a.logw + (int64_t)b * a.Pp + i0;
+        const double2 g01 = *reinterpret_cast<const double2*>(src);
+        const double2 g23 = *reinterpret_cast<const double2*>(src + 2);
+        const double g[kItems] = {g01.x, g01.y, g23.x, g23.y};
+#pragma unroll
+        for (int q = 0; q < kItems; ++q) c[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
+    }
+#pragma unroll
+    for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + c[q];
+    const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
+    if (lane == 63) s_w[wid] = incl;
+    if (threadIdx.x == 0) {  // rand() of hmm_pf_resample.jl:27
+        Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
+        const double r = u01(stream_next(rs));
+        s_r = r;
+        a.rsu[b] = r;
+    }
+    __syncthreads();
+    const unsigned long long W = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) finish_segment(a, b, W, true);
+    if (!resample) return;  // (uniform) last observation of the data set: no resampling (:62)
+    unsigned long long base = incl - c[kItems - 1];
+    for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
+    systematic_boundaries(a, b, 0, 0ull, base, c, W, s_r);
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------

@@ -238,7 +238,8 @@ class ParticleFilter:
         self.ess_frac = float(ess_frac)
 
     def set_propagate_variant(self, rpl: int):
-        """Propagation-kernel variant (0 default, 1 static, 2/4 LDS queue, 16/32 compaction); never changes a result."""
+        """Propagation-kernel variant (0 default, 1 static, 2/4 LDS queue, 16/32 compaction, 33 compaction with small
+        filters laid end to end over the workgroups); never changes a result."""
         self._check(self._lib.dpomp_set_propagate_variant(self._h, int(rpl)))
 
     def _theta_matrix(self, theta) -> np.ndarray:

@@ -196,9 +196,12 @@ int dpomp_set_ess_threshold(dpomp_handle* h, double ess_frac);
 
 /* Tuning: variant of the propagation kernel.  0 = library default (per observation interval: workgroup
  * compaction on a launch of at least 4096 waves unless the previous call measured a lane utilisation of 0.9 or more for that
- * interval, one particle per lane otherwise; see dpomp_get_lane_utilisation); 1 = one particle per lane; 2, 4 =
- * workgroup-local LDS queue with that many particles per lane and dynamic lane refill; 16, 32 = one particle per
- * lane with workgroup-level compaction every that many events.  Results do not depend on it. */
+ * interval, one particle per lane otherwise; see dpomp_get_lane_utilisation.  Under the compaction schedule the default
+ * lays filters of at most 512 particles end to end over the workgroups, so that filters of the reference's default
+ * size -- 200 particles -- fill every lane); 1 = one particle per lane; 2, 4 = workgroup-local LDS queue with that many
+ * particles per lane and dynamic lane refill; 16, 32 = one particle per lane with workgroup-level compaction every
+ * that many events, one filter per workgroup column; 33 = as 32 with the end-to-end layout wherever it applies
+ * (P <= 512).  Results do not depend on it. */
 int dpomp_set_propagate_variant(dpomp_handle* h, int variant);
 
 /* ---- the particle filter ------------------------------------------------------- */
@@ -208,18 +211,25 @@ int dpomp_pf_loglik(dpomp_handle* h, const double* theta, int64_t B, int64_t P, 
                     int64_t seg_base, double* out_ll, uint32_t* out_status);
 
 /* dpomp_pf_loglik for callers that cannot allocate device memory.  It has NO counterpart in the reference: it exists
- * for callers that must not call hipMalloc -- code under HIP graph capture, tight serving loops, harnesses that forbid
- * allocation.  Same arguments, same results bit for bit as dpomp_pf_loglik (whatever resampler / ESS threshold the
- * handle is set to), but every working buffer of the call lives in one static device array of
+ * for callers that must not call hipMalloc -- tight serving loops, harnesses that forbid allocation, processes whose
+ * device memory is fully budgeted.  Same arguments, same results bit for bit as dpomp_pf_loglik (whatever resampler /
+ * ESS threshold the handle is set to), but every working buffer of the call lives in one static device array of
  * DPOMP_STATIC_MAX_BYTES that each GPU the library runs on holds until the process ends; the call performs no
- * hipMalloc / hipFree / hipHostMalloc / event creation (per-kernel profiling is off for it).  Calls whose working set
+ * hipMalloc / hipFree / hipHostMalloc / event or stream creation (per-kernel profiling is off for it;
+ * dpomp_debug_alloc_count() does not move across it).  Like every filter call it ends with a device-to-host copy of
+ * the results and a synchronisation of the stream, so it is NOT capturable into a HIP graph.  Calls whose working set
  * (about (8 S + 20) bytes per particle, plus 8 with resamplers 2/3) exceeds the array, or with
  * B > DPOMP_STATIC_MAX_SEGMENTS, are rejected with DPOMP_EINVAL.  All calls on one GPU share that GPU's array, from
- * every handle and thread: calls that overlap on one GPU race -- serialise them. */
+ * every handle and thread: calls that overlap on one GPU race -- serialise them.
+ * DPOMP_STATIC_MAX_BYTES is a build-time constant of the library (default 16 MiB; `DPOMP_STATIC_MAX_BYTES=<bytes>
+ * python discretepomp.jl_amd/build.py` builds another size); dpomp_static_max_bytes() returns the loaded library's. */
+#ifndef DPOMP_STATIC_MAX_BYTES
 #define DPOMP_STATIC_MAX_BYTES (16u << 20)
+#endif
 #define DPOMP_STATIC_MAX_SEGMENTS 4096
 int dpomp_pf_loglik_static(dpomp_handle* h, const double* theta, int64_t B, int64_t P, uint64_t seed,
                            int64_t seg_base, double* out_ll, uint32_t* out_status);
+int64_t dpomp_static_max_bytes(void);
 
 /* Device-resident populations for the incremental form. */
 int dpomp_pop_alloc(dpomp_handle* h, int64_t B, int64_t P, dpomp_pop** out);
@@ -292,6 +302,10 @@ int dpomp_get_null_bracket_ms(dpomp_handle* h, double* ms);
  * of a one-particle-per-lane schedule.  -1 if that interval has not run yet (or ran in the single-workgroup kernel).
  * The automatic propagate variant uses this figure to decide, per interval, whether workgroup compaction pays. */
 int dpomp_get_lane_utilisation(dpomp_handle* h, int obs_index, double* util);
+/* Number of allocating HIP calls (hipMalloc, hipHostMalloc, hipEventCreate, hipStreamCreate) the library has made in
+ * this process so far -- every such call site goes through one counter.  Test hook: the difference across a call is
+ * zero for an entry point that allocates nothing. */
+long long dpomp_debug_alloc_count(void);
 /* Gillespie events executed by the last pf call (sum over all particles). */
 int dpomp_last_event_count(dpomp_handle* h, uint64_t* events);
 

@@ -41,10 +41,12 @@ def test_device_numerics_match_oracle_bitwise(sis, orc):
     assert np.array_equal(ex, orc.dexp(-37.0 * x))
 
 
-@pytest.mark.parametrize("rpl", [0, 1, 2, 4, 16, 32])   # 0 = default: whole-filter kernel for P <= 256
+# 0 = default: whole-filter kernel for P <= 256; 33 = compaction kernel with small filters laid end to end over the workgroups
+@pytest.mark.parametrize("rpl", [0, 1, 2, 4, 16, 32, 33])
 @pytest.mark.parametrize("P", [1, 63, 64, 65, 200, 256, 257, 1000, 1024, 1025, 4097])
 def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
-    """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane)."""
+    """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane; workgroup compaction,
+    also with filters laid end to end)."""
     theta = [0.003, 0.1]
     sis.set_propagate_variant(rpl)
     pop = sis.alloc_population(1, P)
@@ -131,7 +133,8 @@ def _synthetic_data(dp, orc, model, theta, T=4, tmax=20.0, seed=99):
 
 
 @pytest.mark.parametrize("name,x0,fd,theta", CASES)
-@pytest.mark.parametrize("generic,rpl", [(False, 0), (True, 0), (False, 1), (True, 1), (False, 4), (True, 2), (False, 16), (True, 32)])
+@pytest.mark.parametrize("generic,rpl", [(False, 0), (True, 0), (False, 1), (True, 1), (False, 4), (True, 2), (False, 16), (True, 32),
+                                         (False, 33), (True, 33)])
 def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rpl):
     """Every catalogue model, compiled built-in evaluator and table-driven generic evaluator,
     equals the oracle (which only knows the generic table)."""
@@ -139,7 +142,7 @@ def test_catalogue_models_match_oracle(dp, orc, name, x0, fd, theta, generic, rp
     y = _synthetic_data(dp, orc, model, theta)
     pf = dp.ParticleFilter(model, y, force_generic=generic)
     pf.set_propagate_variant(rpl)
-    P = 200 if rpl == 0 else 777   # 200: the reference's default npf, served by the whole-filter kernel
+    P = 200 if rpl in (0, 33) else 777   # 200: the reference's default npf, served by the whole-filter kernel
     pop = pf.alloc_population(1, P)
     ll = pf.partial_log_likelihood(pop, theta, 1, len(y), seed=42)
     ref = orc.pf_loglik(pf.desc, P, theta, seed=42)
@@ -684,4 +687,35 @@ def test_many_tiles_other_resamplers_and_ess_sums(dp, orc, pooley, rs_type, ess,
     ref = orc.pf_partial(pf.desc, host, theta, 1, 1, seed=77, rs_type=rs_type, nthreads=8, ess_frac=ess)
     assert ll[0] == ref.ll and pf.last_event_count() == ref.events and pf.last_status[0] == ref.status
     assert np.array_equal(pop.download(0), host)
+    pf.close()
+
+
+@pytest.mark.parametrize("rpl", [0, 32, 33])
+@pytest.mark.parametrize("B,P", [(7, 200), (33, 100), (5, 64), (3, 511), (9, 300), (4, 1500), (2100, 200)])
+def test_many_filters_per_workgroup_match_oracle(dp, orc, pooley, B, P, rpl):
+    """Filters with DIFFERENT parameters share workgroups when they are laid end to end (33; the default for thousands
+    of small filters, 2100 x 200): every filter must still equal the oracle run of its own parameters -- populations,
+    event counts, log-likelihoods -- in one call and one observation per call (the SMC^2 increments)."""
+    rng = np.random.default_rng(B * 1000 + P)
+    theta = np.stack([rng.uniform(0.0015, 0.0045, B), rng.uniform(0.05, 0.2, B)])
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
+    pf.set_propagate_variant(rpl)
+    pop = pf.alloc_population(B, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=77, seg_base=5)
+    events = pf.last_event_count()
+    pop2 = pf.alloc_population(B, P)
+    inc = np.zeros(B)
+    for k in range(1, pf.n_obs + 1):
+        inc += pf.partial_log_likelihood(pop2, theta, k, k, seed=77, seg_base=5)
+    want_events = 0
+    check = range(B) if B <= 64 else list(range(0, B, 97)) + [B - 1]
+    for b in check:
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=77, seg=5 + b)
+        want_events += ref.events
+        assert ll[b] == ref.ll, (b, ll[b], ref.ll)
+        assert abs(inc[b] - ref.ll) < 1e-12
+        assert np.array_equal(pop.download(b), ref.pop), b
+        assert np.array_equal(pop2.download(b), ref.pop), b
+    if B <= 64:
+        assert events == want_events
     pf.close()

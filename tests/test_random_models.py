@@ -62,7 +62,7 @@ def test_random_models_filter_matches_oracle(dp, orc, seed):
     model.max_events_per_interval = 5000
     y = [dp.Observation(t, 1, 1.0, [int(rng.integers(5, 60))]) for t in (1.0, 2.5, 4.0)]
     pf = dp.ParticleFilter(model, y)
-    pf.set_propagate_variant(int(rng.choice([0, 1, 2, 4, 16, 32])))
+    pf.set_propagate_variant(int(rng.choice([0, 1, 2, 4, 16, 32, 33])))
     P = int(rng.integers(100, 1400)) if seed % 2 else int(rng.integers(2, 257))
     pop = pf.alloc_population(2, P)
     th2 = np.stack([theta, theta * 1.3], axis=1)

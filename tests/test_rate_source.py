@@ -52,18 +52,18 @@ def test_oracle_runs_the_same_source_on_the_host(dp, orc, pooley, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [1, 32])
-def test_rate_source_filter_matches_oracle(dp, orc, pooley, tmp_path, variant):
+@pytest.mark.parametrize("variant,P", [(1, 3000), (32, 3000), (33, 300)])
+def test_rate_source_filter_matches_oracle(dp, orc, pooley, tmp_path, variant, P):
     orc.set_user_rates_from_source(SOURCE, str(tmp_path))
     pf = dp.ParticleFilter(_model(dp), pooley)
     pf.set_propagate_variant(variant)
     theta = np.array([[0.003, 0.0035], [0.1, 0.12], [0.01, 0.02], [0.02, 0.0]])
-    pop = pf.alloc_population(2, 3000)
+    pop = pf.alloc_population(2, P)
     ll = pf.partial_log_likelihood(pop, theta, 1, pf.n_obs, seed=13)
     for b in range(2):
-        ref = orc.pf_loglik(pf.desc, 3000, theta[:, b], seed=13, seg=b)
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=13, seg=b)
         assert ll[b] == ref.ll and np.array_equal(pop.download(b), ref.pop)
-    assert pf.last_event_count() == sum(orc.pf_loglik(pf.desc, 3000, theta[:, b], seed=13, seg=b).events for b in range(2))
+    assert pf.last_event_count() == sum(orc.pf_loglik(pf.desc, P, theta[:, b], seed=13, seg=b).events for b in range(2))
     pf.close()
 
 

@@ -30,7 +30,7 @@ def test_compiled_table_equals_interpreter_and_oracle(dp, orc, name, x0, fd, the
     cat = dp.ParticleFilter(model, y)
     assert (jit.evaluator, tab.evaluator, cat.evaluator) == (dp._abi.EVALUATOR_TABLE_COMPILED, dp._abi.EVALUATOR_TABLE,
                                                              dp._abi.EVALUATOR_BUILTIN)
-    for variant, P in ((0, 200), (0, 3000), (1, 777), (2, 777), (4, 1500), (16, 1500), (32, 1500)):
+    for variant, P in ((0, 200), (0, 3000), (1, 777), (2, 777), (4, 1500), (16, 1500), (32, 1500), (33, 300)):
         ref = orc.pf_loglik(jit.desc, P, theta, seed=42)
         for pf in (jit, tab, cat):
             pf.set_propagate_variant(variant)
@@ -103,7 +103,7 @@ def test_user_source_models_run_every_schedule(dp, orc, pooley, tmp_path):
     pf = dp.ParticleFilter(model, pooley)
     assert pf.evaluator == dp._abi.EVALUATOR_SOURCE
     sis = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley)
-    for variant in (1, 2, 4, 16, 32):
+    for variant in (1, 2, 4, 16, 32, 33):
         pf.set_propagate_variant(variant)
         assert pf.loglik([0.003, 0.1], 5000, seed=7)[0] == sis.loglik([0.003, 0.1], 5000, seed=7)[0]
     pf.close()

@@ -93,3 +93,49 @@ def test_static_entry_point_rejects_what_does_not_fit(dp, pooley):
     # the largest SIS call that fits (36 B per particle + control block) still runs and agrees
     _same(*_pair(pf, [0.003, 0.1], 460000, seed=2))
     pf.close()
+
+
+def test_static_entry_point_makes_no_allocating_call(dp, pooley):
+    """The property the entry point exists for: across its calls the library makes no hipMalloc / hipHostMalloc /
+    hipEventCreate / hipStreamCreate (every such call site of the library bumps dpomp_debug_alloc_count), and the free
+    device memory does not move -- whatever the shape, resampler or mode, first call of a shape included.  The
+    allocating entry point does move the counter on the first call of a new shape."""
+    import torch
+    lib = dp._abi.load_library()
+    assert lib.dpomp_static_max_bytes() == dp._abi.STATIC_MAX_BYTES
+    handles = []
+    for rs_type, ess in [(1, 0.0), (2, 0.0), (3, 0.0), (1, 0.5), (2, 0.5)]:
+        pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=rs_type)
+        if ess:
+            pf.set_ess_threshold(ess)
+        handles.append(pf)
+    theta = np.array([[0.003, 0.0032, 0.0025], [0.1, 0.1, 0.08]])
+    ll = np.zeros(400)
+    big = np.ascontiguousarray(np.tile(np.array([0.003, 0.1]), (400, 1)))
+
+    def static_call(pf, th, B, P, seed):
+        rc = lib.dpomp_pf_loglik_static(pf._h, th.ctypes.data_as(C.POINTER(C.c_double)), B, P, seed, 0,
+                                        ll.ctypes.data_as(C.POINTER(C.c_double)), None)
+        assert rc == 0, lib.dpomp_last_error(pf._h).decode()
+
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    n0 = lib.dpomp_debug_alloc_count()
+    for pf in handles:
+        th = pf._theta_matrix(theta)
+        static_call(pf, th, 3, 30000, 11)       # multi-kernel path, several tiles per filter
+        static_call(pf, th, 2, 777, 12)         # a new, smaller shape
+        static_call(pf, th, 1, 200, 13)         # whole-filter kernel (systematic, non-adaptive) / one tile
+        static_call(pf, big, 300, 64, 14)       # hundreds of small filters in one call (rows are padded to 1024 slots)
+        static_call(pf, th, 3, 30000, 15)       # the first shape again
+    assert lib.dpomp_debug_alloc_count() == n0, "dpomp_pf_loglik_static made an allocating HIP call"
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "free device memory moved across dpomp_pf_loglik_static calls"
+    # the hook itself works: the allocating entry point allocates on the first call of a shape, not on the second
+    handles[0].loglik(theta, 12345, seed=1)
+    n1 = lib.dpomp_debug_alloc_count()
+    assert n1 > n0
+    handles[0].loglik(theta, 12345, seed=2)
+    assert lib.dpomp_debug_alloc_count() == n1
+    for pf in handles:
+        pf.close()
