@@ -29,10 +29,83 @@ HBM_MEASURED_COPY_GBS = 6290.0  # measured float4-copy rate of the chip (79 % of
 # k_propagate_c<RSir<2>,32>: 2 x (10 stream step + 3 uniform), 17 log, 8 division + 2 range test, 6 rates, 5 event choice
 # and state update, 2 clock).  Measured issue cost per wave64 instruction on gfx950 (tools/valu_rate_probe.hip ->
 # profiles/r01_final/valu_issue_rates.json): FP64, 64-bit integer and three-operand 32-bit ops 4 cycles, plain
-# two-operand 32-bit ops (xor/add/or/and/shift: 12 of the 66) ~0.65 of that, v_rcp_f64 3.4 x.  Hence
-# 53 + 12 * 0.65 + 3.4 = 64.2 issue slots = 257 cycles per 64 events per SIMD; 1024 SIMDs at 2.4 GHz.
-VALU_CYCLES_PER_WAVE_EVENT = (53 + 12 * 0.65 + 3.4) * 4
+# two-operand 32-bit ops (xor/add/sub/or/and/shift: 15 of the 66) ~0.65 of that, v_rcp_f64 3.4 x.  Hence
+# 50 + 15 * 0.65 + 3.4 = 63.15 issue slots = 253 cycles per 64 events per SIMD; 1024 SIMDs at 2.4 GHz.  The count is
+# taken from the ISA of the build by tools/isa_loop_count.py (-> profiles/*/valu_ceilings.json, read below; the
+# constants here are the fallback when no such file is present).
+VALU_CYCLES_PER_WAVE_EVENT = (50 + 15 * 0.65 + 3.4) * 4
 VALU_CEILING_EVENTS_PER_S = 1024 * 2.4e9 * 64 / VALU_CYCLES_PER_WAVE_EVENT
+
+
+def valu_ceiling(family="sis"):
+    """(events/s ceiling of the compaction kernel's event loop, where it came from) -- latest profiles/*/valu_ceilings.json."""
+    root = os.path.join(ROOT, "profiles")
+    best = (VALU_CEILING_EVENTS_PER_S, "bench.py constant")
+    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        f = os.path.join(root, d, "valu_ceilings.json")
+        if os.path.exists(f):
+            for label, v in json.load(open(f))["kernels"].items():
+                if label.startswith(family + " ") and "k_propagate_c" in label and "ceiling_events_per_s" in v:
+                    best = (float(v["ceiling_events_per_s"]), f"profiles/{d}/valu_ceilings.json: {v['valu']} VALU instructions "
+                            f"({v['valu_light']} light, {v['valu_trans']} transcendental) = {v['issue_slots_per_event']} issue slots per event")
+    return best
+
+
+def hbm_scale_summary():
+    """The streaming kernels where the working set exceeds the 256 MiB Infinity Cache, from the latest committed
+    rocprofv3 passes (profiles/*/hbm_scale/by_launch_shape.json: 16.8 M particles per launch = 16384 workgroups):
+    bytes really moved / average duration, as a fraction of 8 TB/s."""
+    root = os.path.join(ROOT, "profiles")
+    out = None
+    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        f = os.path.join(root, d, "hbm_scale", "by_launch_shape.json")
+        if not os.path.exists(f):
+            continue
+        shapes = json.load(open(f))
+        n = 16384 * 1024  # particles of the 16384-workgroup launches
+        moved = {"k_wsum": 16 * n, "k_offsets<true>": 12 * n, "k_gather": (4 + 8 * 4) * n}  # k_gather: the SEIR shape (S = 4)
+        cur = {"source": f"profiles/{d}/hbm_scale/by_launch_shape.json", "particles_per_launch": n, "working_set": "576-832 MiB"}
+        for kname, nbytes in moved.items():
+            v = shapes.get("dpomp::" + kname, {}).get("16384 workgroups")
+            if v:
+                cur[kname.split("<")[0]] = {"avg_us": v["avg_us"], "moved_bytes": nbytes, "pmc_hbm_bytes": v.get("hbm_bytes_per_launch_corrected"),
+                                            "frac_of_8TBs": round(nbytes / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)}
+        out = cur
+    return out
+
+
+SMC2_PRIOR_BOX = ([0.0, 0.0, 0.0], [0.02, 0.6, 0.4])  # tightened from the reference's weak prior U(0,1)^3 (hmm_examples.jl:33-35)
+
+
+def smc2_config4(dp, bank_factory, n_theta, npf, distributed, seed=3, reps=2, data=None):
+    """BASELINE configuration 4: SMC^2 (run_pibis, src/hmm_ibis.jl:12-135) on SEIR with n_theta theta-particles x npf
+    state particles, the theta-particles sharded over the ranks when `distributed`; at theta-level resampling
+    (:70-75) populations whose ancestor lives on another rank travel in one all-to-all.  Runs `reps` times with the
+    same seed (the first pays allocations and the clock ramp) and reports the last: the RNG is keyed by global indices,
+    so the evidence is the same bits for every number of ranks."""
+    import numpy as np
+    y = data or dp.get_observations(os.path.join(ROOT, "tests", "golden", "seir_synthetic.csv"))
+    model = dp.generate_model("SEIR", [100, 0, 1, 0])
+    prior = dp.UniformProductPrior(*SMC2_PRIOR_BOX)
+    out = None
+    for rep in range(reps):
+        rng = np.random.default_rng(seed)
+        theta0 = prior.rand(rng, n_theta)
+        bank = bank_factory(model, y)
+        t0 = time.perf_counter()
+        try:
+            res = dp.run_pibis(bank, prior, theta0, 0.3, True, 1.002, npf, seed=seed, rng=rng, verbose=False, distributed=distributed)
+        finally:
+            close = getattr(bank, "close", None)
+            if close:
+                close()
+        out = {"seconds": time.perf_counter() - t0, "n_resample": int(res.n_resample),
+               "minus_ln_evidence": [float(v) for v in np.atleast_1d(res.bme)],
+               "posterior_mean": [float(v) for v in res.mu], "acceptance_rate": float(res.acceptance_rate), "status": int(res.status),
+               "rows_received": int(res.migration["rows_received"]) if res.migration else 0,
+               "block": int(res.migration["block"]) if res.migration else n_theta,
+               "theta_particles": n_theta, "state_particles": npf}
+    return out
 
 
 def algorithmic_bytes(P, S):
@@ -69,7 +142,9 @@ def pmc_traffic(kernel):
             f = os.path.join(root, d, sub, "pmc_hbm_traffic.json")
             if os.path.exists(f):
                 for name, v in json.load(open(f)).items():
-                    if name.split("::")[-1].split("<")[0] == kernel:
+                    base = name.replace("void ", "")
+                    base = base[len("dpomp::"):] if base.startswith("dpomp::") else base
+                    if base.split("<")[0] == kernel:
                         best = (v.get("hbm_bytes_per_launch_corrected"), os.path.join(d, sub).rstrip("/"))
     return best
 
@@ -130,13 +205,9 @@ def _free_port():
 
 def launch_ranks(args, argv):
     """`bench.py --gpus N` started as a plain process: start N ranks (one per GPU) with torch.distributed.run as a
-    CHILD process -- this process has not touched the GPU and never does -- and exit with its code."""
+    CHILD process and exit with its code.  This process makes no GPU call at all -- not even a device count: every
+    rank checks for itself that its LOCAL_RANK names a visible GPU and fails the run otherwise."""
     import subprocess
-    if not args.dry_run:
-        import torch
-        n = torch.cuda.device_count()  # counts devices without initialising the GPU
-        if n < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n} GPU(s) visible")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
@@ -180,6 +251,11 @@ def main():
     ap.add_argument("--propagate-variant", type=int, default=0, help="0 = library default; see dpomp_set_propagate_variant")
     ap.add_argument("--profile-every", type=int, default=10,
                     help="HIP-event brackets around the kernels of every n-th timed step (the markers cost GPU time)")
+    ap.add_argument("--no-smc2", action="store_true", help="skip the SMC^2 leg (BASELINE configuration 4) after the timed region")
+    ap.add_argument("--write-smc2-reference", action="store_true",
+                    help="single GPU only: store the SMC^2 leg's evidence as the committed value runs on more GPUs must reproduce bit for bit")
+    ap.add_argument("--smc2-theta", type=int, default=512)
+    ap.add_argument("--smc2-particles", type=int, default=1 << 16)
     ap.add_argument("--dry-run", action="store_true",
                     help="launch plumbing only (gloo rendezvous, rank accounting, no GPU, no filter): for the CPU test of --gpus N")
     args = ap.parse_args()
@@ -280,6 +356,31 @@ def main():
         dist.all_reduce(ev)
         events = float(ev[0])
 
+    # BASELINE configuration 4 after the timed region: the one path with real inter-GPU traffic (theta-level migration)
+    smc2 = None
+    if not args.no_smc2:
+        leg = smc2_config4(dp, lambda model, y: dp.ParticleFilter(model, y, device=local_rank), args.smc2_theta, args.smc2_particles,
+                           distributed=dist is not None)
+        rows = [leg["rows_received"]]
+        if dist is not None:
+            r_all = torch.zeros(world, dtype=torch.int64, device="cuda")
+            dist.all_gather_into_tensor(r_all, torch.tensor([leg["rows_received"]], dtype=torch.int64, device="cuda"))
+            rows = [int(v) for v in r_all.cpu()]
+            t_all = torch.tensor([leg["seconds"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+            leg["seconds"] = float(t_all[0])
+        row_bytes = 4 * 4 * ((args.smc2_particles + 1023) // 1024 * 1024)  # int32 state, 4 components, rows padded to 1024 slots
+        ref_file = os.path.join(ROOT, "profiles", "r03", "smc2_config4_single_gpu.json")
+        ref = json.load(open(ref_file)) if os.path.exists(ref_file) else None
+        same_shape = ref and ref.get("theta_particles") == args.smc2_theta and ref.get("state_particles") == args.smc2_particles
+        smc2 = {"workload": f"SEIR, {args.smc2_theta} theta-particles x {args.smc2_particles} state particles, run_pibis (SMC^2), "
+                            f"theta-particles sharded over {world} rank(s)",
+                "seconds": round(leg["seconds"], 4), "n_resample": leg["n_resample"], "rows_received_per_rank": rows,
+                "bytes_received_per_rank": [r * row_bytes for r in rows], "minus_ln_evidence": leg["minus_ln_evidence"],
+                "posterior_mean": leg["posterior_mean"], "acceptance_rate": round(leg["acceptance_rate"], 4), "status": leg["status"],
+                "particle_steps_per_increment_pass": args.smc2_theta * args.smc2_particles,
+                "equals_committed_single_gpu_evidence": (leg["minus_ln_evidence"] == ref["minus_ln_evidence"]) if same_shape else None,
+                "committed_single_gpu_evidence": "profiles/r03/smc2_config4_single_gpu.json" if same_shape else None}
     if rank == 0:
         stats = pf.kernel_stats()
         alg = algorithmic_bytes(P, S)
@@ -306,9 +407,9 @@ def main():
         rk = "k_offsets" if "k_offsets" in kernels else "k_wsum"
         g = kernels.get(rk, {})
         traffic = pmc_traffic(rk) or (None, "none")
-        roofline = {
+        memory_stage = {
             "kernel": rk,
-            "bound": "hbm",
+            "bound": "hbm (launch latency at this size: the 36 MiB working set is served from L2 / Infinity Cache)",
             "achieved": g.get("achieved_GBs"),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -320,34 +421,50 @@ def main():
             "achieved_moved_bytes": g.get("moved_GBs"),
             "frac_moved_bytes": round(g.get("moved_GBs", 0.0) / HBM_PEAK_GBS, 4) if g else None,
             "peak_measured": HBM_MEASURED_COPY_GBS,
-            "frac_moved_bytes_of_peak_measured": round(g.get("moved_GBs", 0.0) / HBM_MEASURED_COPY_GBS, 4) if g else None,
             "working_set_bytes": P * (2 * 4 * S + 8 + 8 + 4),  # two state buffers, log-weights, fixed-point weights, boundaries
-            "timing": f"HIP events stamped with each kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the "
-                      f"launch stream), kernels of every {max(1, args.profile_every)}th timed step; the same quantity rocprofv3 reports per "
-                      "dispatch (profiles/)",
-            "note": "memory-bound stage (normalise+scan; gather fused into k_propagate); k_propagate, which holds >95% of "
-                    "the time, is FP64-VALU/divergence bound and is reported under 'propagate' with its own ceiling",
+            "beyond_infinity_cache": hbm_scale_summary(),
         }
         mem_us = sum(kernels[k]["avg_us"] for k in ("k_wsum", "k_scan_blocks", "k_offsets", "k_gather") if k in kernels)
         mem_bytes = sum(alg[k] for k in ("k_wsum", "k_offsets", "k_gather") if k in kernels)
-        roofline["stage_achieved_GBs"] = round(mem_bytes / (mem_us * 1e-6) / 1e9, 1) if mem_us else None
+        memory_stage["stage_achieved_GBs"] = round(mem_bytes / (mem_us * 1e-6) / 1e9, 1) if mem_us else None
         prop = kernels.get("k_propagate", {})
+        ceiling, ceiling_source = valu_ceiling("sis")
+        events_per_launch = events / world / args.steps / T
         propagate = {
             "avg_us": prop.get("avg_us"),
-            "events_per_s": round(events / world / args.steps / (prop.get("avg_us", 1) * T * 1e-6)) if prop else None,
+            "events_per_s": round(events_per_launch / (prop.get("avg_us", 1) * 1e-6)) if prop else None,
+            "events_per_launch": round(events_per_launch),
             "events_per_particle_per_call": round(events / world / args.steps / P, 1),
             "hbm_achieved_GBs": prop.get("achieved_GBs"),
             "bound": "VALU issue + wave divergence (not HBM, not MFMA)",
-            "valu_ceiling_events_per_s": round(VALU_CEILING_EVENTS_PER_S),
+            "valu_ceiling_events_per_s": round(ceiling),
             "lane_utilisation_static_schedule": [round(float(u), 3) for u in pf.lane_utilisation()],
         }
+        # The dominant kernel (97 % of GPU time) has neither an HBM nor an MFMA roof: its ceiling is VALU issue --
+        # SIMDs x clock x 64 lanes / (4 cycles x issue slots per event), issue slots from the ISA of this build.
+        ptraffic = pmc_traffic("k_propagate_c") or pmc_traffic("k_propagate") or (None, "none")
+        roofline = {
+            "kernel": "k_propagate (k_propagate_c<RSir<2>,32>)",
+            "bound": "valu-issue",
+            "achieved": propagate["events_per_s"],
+            "peak": round(ceiling),
+            "unit": "events/s",
+            "frac": round(propagate["events_per_s"] / ceiling, 4) if propagate.get("events_per_s") else None,
+            "traffic": ptraffic[0],
+            "traffic_source": ptraffic[1],
+            "share_of_kernel_time": round(prop["avg_us"] * prop["launches"] / sum(k["avg_us"] * k["launches"] for k in kernels.values()), 3) if prop else None,
+            "algorithmic_events_per_launch": propagate["events_per_launch"],
+            "algorithmic_bytes_per_launch": alg["k_propagate"],
+            "peak_source": ceiling_source + "; 1024 SIMDs x 2.4 GHz x 64 lanes / (4 cycles x issue slots)",
+            "timing": f"HIP events stamped with each kernel's own begin and end (hipExtLaunchKernelGGL start/stop events on the "
+                      f"launch stream), kernels of every {max(1, args.profile_every)}th timed step; the same quantity rocprofv3 reports per "
+                      "dispatch (profiles/)",
+            "note": "frac = events per launch / average launch duration / VALU-issue ceiling; the memory-bound stage "
+                    "(normalise + scan; the resampling gather runs inside the next propagation's loads) is under memory_stage",
+            "memory_stage": memory_stage,
+        }
         if propagate.get("events_per_s"):
-            propagate["valu_frac"] = round(propagate["events_per_s"] / VALU_CEILING_EVENTS_PER_S, 3)
-            # the kernel that dominates the step has neither an HBM nor an MFMA roof: its ceiling is VALU issue
-            roofline["dominant_kernel"] = {"name": "k_propagate", "share_of_kernel_time": round(
-                prop["avg_us"] * prop["launches"] / sum(k["avg_us"] * k["launches"] for k in kernels.values()), 3),
-                "bound": "valu-issue (FP64 + 64-bit integer), see 'propagate'", "achieved_events_per_s": propagate["events_per_s"],
-                "ceiling_events_per_s": round(VALU_CEILING_EVENTS_PER_S), "frac": propagate["valu_frac"]}
+            propagate["valu_frac"] = roofline["frac"]
         mean_ll = float(np.mean(lls))
         result = {
             "metric": "particle-steps/sec",
@@ -372,6 +489,13 @@ def main():
             "propagate": propagate,
             "kernels": kernels,
         }
+        if smc2 is not None:
+            result["smc2_config4"] = smc2
+            if args.write_smc2_reference and world == 1:
+                with open(os.path.join(ROOT, "profiles", "r03", "smc2_config4_single_gpu.json"), "w") as f:
+                    json.dump({"theta_particles": args.smc2_theta, "state_particles": args.smc2_particles, "seed": 3,
+                               "minus_ln_evidence": smc2["minus_ln_evidence"], "posterior_mean": smc2["posterior_mean"],
+                               "n_resample": smc2["n_resample"], "seconds_single_gpu": smc2["seconds"]}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             # log-ML abs error vs the CPU path at identical seed, on the CPU baseline's own run (by default the whole
             # 2^20-particle workload): bit parity expected

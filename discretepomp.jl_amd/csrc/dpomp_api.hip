@@ -71,7 +71,7 @@ constexpr int kDefaultPropVariant = 32;  // workgroup compaction, first live-lan
 // wins by 2-7 %.
 constexpr double kCompactionBelowUtil = 0.90;
 constexpr double kBoostChainFrac = 0.72;  // head start of the last workgroups: share of a wave's event chain (tools/ab_probe.py)
-constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup re-sums the tile sums (<= 16 KB from L2)
+constexpr int kFusedScanMaxTiles = 2048;  // k_offsets<true>: every workgroup sums <= 64 second-level sums + <= 31 tile sums itself
 
 // Per rate evaluator: the one-particle-per-lane kernel and the queue-refill kernels with 2 and 4
 // particles per lane (chosen by how many particles the launch has, see pick_prop).
@@ -208,7 +208,7 @@ struct dpomp_handle {
 
 struct dpomp_pop {
     int64_t B = 0, P = 0, Pp = 0;
-    int nblk = 0, S = 0, K = 0, T = 0;
+    int nblk = 0, nsuper = 0, S = 0, K = 0, T = 0;
     int32_t* state[2] = {nullptr, nullptr};
     int cur = 0;
     double* logw = nullptr;
@@ -231,6 +231,7 @@ struct dpomp_pop {
     char* h_result = nullptr;    // pinned host staging: result download and parameter upload of a call are true
     double* h_theta = nullptr;   // asynchronous copies (pageable memory makes each a blocking, staged transfer)
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
+    unsigned long long* supersum = nullptr;  // [T][B][nsuper] sums of 32 tile sums each (inside ctl)
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]      (inside ctl)
     uint32_t* status = nullptr;            // [B]      (inside ctl)
@@ -410,8 +411,8 @@ void pop_release(dpomp_pop* p) {
 }
 
 // Shape of a population and of its control block:
-// [ll B f64][events u64][status B u32, padded to 8 B][per-interval counters][segmax T*B u64] -> one clear and one
-// result download per call.  Per observation interval: executed events and 64 * sum of per-wave maxima, as partial
+// [ll B f64][events u64][status B u32, padded to 8 B][per-interval counters][segmax T*B u64][second-level weight sums
+// T*B*ceil(nblk/32) u64] -> one clear and one result download (of the first four) per call.  Per observation interval: executed events and 64 * sum of per-wave maxima, as partial
 // sums on 128-byte lines of their own (dpomp_kernels.h: sched_add).
 void pop_set_shape(dpomp_handle* h, dpomp_pop* p, int64_t B, int64_t P) {
     p->B = B;
@@ -425,7 +426,9 @@ void pop_set_shape(dpomp_handle* h, dpomp_pop* p, int64_t B, int64_t P) {
     const size_t n_sc = (size_t)p->T * kSchedStride * 8;
     p->sched_offset = n_ll + n_ev + n_st;
     p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
-    p->ctl_bytes = p->ctl_result_bytes + n_sm;
+    p->nsuper = (p->nblk + kSuperTiles - 1) / kSuperTiles;
+    // (filters of at most 32 tiles have a single group: k_offsets<true> sums their tile sums directly)
+    p->ctl_bytes = p->ctl_result_bytes + n_sm + (p->nblk > kSuperTiles ? (size_t)p->T * B * p->nsuper * kSuperStride * 8 : 0);
 }
 void pop_bind_ctl(dpomp_pop* p) {
     const size_t n_ll = (size_t)p->B * 8, n_ev = 8;
@@ -433,6 +436,7 @@ void pop_bind_ctl(dpomp_pop* p) {
     p->events = reinterpret_cast<unsigned long long*>(p->ctl + n_ll);
     p->status = reinterpret_cast<uint32_t*>(p->ctl + n_ll + n_ev);
     p->segmax = reinterpret_cast<unsigned long long*>(p->ctl + p->ctl_result_bytes);
+    p->supersum = p->segmax + (size_t)p->T * p->B;
 }
 
 int check_pop_dims(dpomp_handle* h, int64_t B, int64_t P) {
@@ -771,6 +775,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.segmax = p->segmax + (size_t)k * B;
             w.blocksum = p->blocksum;
             w.blockprefix = p->blockprefix;
+            w.supersum = p->supersum + (size_t)k * B * p->nsuper * kSuperStride;
             w.wtot = p->wtot;
             w.ll = p->ll;
             w.status = p->status;

@@ -1320,6 +1320,9 @@ struct WeightArgs {
     const unsigned long long* segmax;   // [B]
     unsigned long long* blocksum;       // [B][nblk]
     unsigned long long* blockprefix;    // [B][nblk] exclusive prefix of blocksum
+    unsigned long long* supersum;       // [B][ceil(nblk / 32)] (stride kSuperStride words: one 128-byte line each) sums of
+                                        // 32 consecutive tile sums of THIS observation (zero when k_wsum starts: the
+                                        // array lives in the control block)
     unsigned long long* wtot;           // [B]
     double* ll;                         // [B] running log-likelihood
     uint32_t* status;                   // [B]
@@ -1405,6 +1408,9 @@ __device__ __forceinline__ void finish_segment(const WeightArgs& a, int b, unsig
     }
 }
 
+constexpr int kSuperTiles = 32;   // tiles per second-level sum (k_wsum -> k_offsets<true>)
+constexpr int kSuperStride = 16;  // u64 between two second-level sums: atomics on one 128-byte line serialise at the L2
+
 // k_wsum: per-tile sum of the fixed-point weights rint(exp(g - max) 2^sh).
 __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     const int b = blockIdx.y, blk = blockIdx.x;
@@ -1426,7 +1432,12 @@ __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.blocksum[(int64_t)b * a.nblk + blk] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        const unsigned long long tile_sum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+        a.blocksum[(int64_t)b * a.nblk + blk] = tile_sum;
+        // second level for k_offsets<true>: 32 tiles to a sum (integer adds commute: the same bits in any order; 32
+        // atomics per word do not queue up)
+        if (tile_sum && a.nblk > kSuperTiles)
+            atomicAdd(&a.supersum[((int64_t)b * ((a.nblk + kSuperTiles - 1) / kSuperTiles) + blk / kSuperTiles) * kSuperStride], tile_sum);
         if (a.ess_frac > 0.0) {
             unsigned long long hi = s_hi[0], lo = s_lo[0];
             for (int w2 = 1; w2 < kBlock / 64; ++w2) add128(hi, lo, s_hi[w2], s_lo[w2]);
@@ -1550,11 +1561,32 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
     if (FUSED) {
         const unsigned long long* bs = a.blocksum + (int64_t)b * a.nblk;
         unsigned long long pre = 0, tot = 0, hi = 0, lo = 0;
-        for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
-            const unsigned long long v = bs[i];
-            tot += v;
-            if (i < blk) pre += v;
-            if (adaptive) add128(hi, lo, a.blocksum2[((int64_t)b * a.nblk + i) * 2], a.blocksum2[((int64_t)b * a.nblk + i) * 2 + 1]);
+        if (adaptive) {  // (also needs every tile's sum of squares)
+            for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
+                const unsigned long long v = bs[i];
+                tot += v;
+                if (i < blk) pre += v;
+                add128(hi, lo, a.blocksum2[((int64_t)b * a.nblk + i) * 2], a.blocksum2[((int64_t)b * a.nblk + i) * 2 + 1]);
+            }
+        } else {
+            // two levels: the sums of 32 tiles each (k_wsum) give the total and the prefix up to this tile's group, the
+            // tile sums of the group the rest -- at most 64 + 31 words per workgroup instead of all nblk tile sums
+            // (every workgroup of a 1024-tile filter used to re-read 8 KB: a third of the kernel's traffic)
+            const int nsuper = (a.nblk + kSuperTiles - 1) / kSuperTiles, g = blk / kSuperTiles;
+            const int t = threadIdx.x;
+            if (a.nblk <= kSuperTiles) {  // (uniform) a single group: its tile sums are all there is
+                if (t < a.nblk) {
+                    tot = bs[t];
+                    if (t < blk) pre = tot;
+                }
+            } else if (t < nsuper) {  // (nsuper <= 64: k_offsets<true> serves at most 2048 tiles)
+                const unsigned long long v = a.supersum[((int64_t)b * nsuper + t) * kSuperStride];
+                tot = v;
+                if (t < g) pre = v;
+            } else if (t >= 64 && t < 64 + kSuperTiles) {
+                const int i = g * kSuperTiles + (t - 64);
+                if (i < blk) pre = bs[i];
+            }
         }
         pre = wave_sum(pre);
         tot = wave_sum(tot);

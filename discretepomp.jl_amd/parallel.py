@@ -104,7 +104,7 @@ class LocalBank:
                 c()
 
 
-def migration_plan(nidx, N: int, world: int, rank: int):
+def migration_plan(nidx, N: int, world: int, rank: int, loopback: bool = False):
     """Who sends which populations to whom when the theta-particles are resampled with global ancestors ``nidx``
     (src/hmm_ibis.jl:70-75) and block ``shard_bounds(N, world, r)`` lives on rank r.  A rank sends each of its
     populations at most ONCE to each rank that needs it (duplicates are expanded by the receiver), so a rank receives
@@ -114,7 +114,11 @@ def migration_plan(nidx, N: int, world: int, rank: int):
     Returns a dict for ``rank``: ``send_rows`` (local row indices, grouped by destination rank in rank order),
     ``send_counts`` / ``recv_counts`` ([world]), ``local_anc`` (for every slot of the block: the local row it copies
     if its ancestor lives here, else the slot itself), ``remote_slots`` and ``remote_pick`` (slot b takes row
-    ``remote_pick`` of the receive buffer)."""
+    ``remote_pick`` of the receive buffer).
+
+    ``loopback`` (test hook): a rank treats ITSELF like any other rank -- populations whose ancestor is local also
+    travel through the collective (send to self) instead of being copied on the device.  Same result; it makes the
+    all-to-all carry data even in a world of one rank."""
     nidx = np.asarray(nidx, dtype=np.int64)
     bounds = [shard_bounds(N, world, r) for r in range(world)]
     owner = np.empty(N, dtype=np.int64)
@@ -123,7 +127,7 @@ def migration_plan(nidx, N: int, world: int, rank: int):
     lo, hi = bounds[rank]
     send_rows, send_counts = [], np.zeros(world, dtype=np.int64)
     for dst, (dlo, dhi) in enumerate(bounds):  # what this rank sends: its rows that block `dst` descends from
-        if dst == rank:
+        if dst == rank and not loopback:
             continue
         anc = nidx[dlo:dhi]
         mine = np.unique(anc[owner[anc] == rank])
@@ -133,13 +137,13 @@ def migration_plan(nidx, N: int, world: int, rank: int):
     src = owner[anc] if hi > lo else np.empty(0, dtype=np.int64)
     recv_counts = np.zeros(world, dtype=np.int64)
     local_anc = np.arange(hi - lo, dtype=np.int64)
-    here = src == rank
+    here = (src == rank) & (not loopback)
     local_anc[here] = anc[here] - lo
     remote_slots = np.flatnonzero(~here)
     remote_pick = np.empty(len(remote_slots), dtype=np.int64)
     offset = 0
     for r in range(world):
-        if r == rank:
+        if r == rank and not loopback:
             continue
         sel = src[remote_slots] == r
         uniq = np.unique(anc[remote_slots][sel])  # the order rank r sends them in
@@ -162,9 +166,9 @@ class ShardedBank(LocalBank):
     most its own block's worth of populations (``last_migration``), not the whole bank.  Results are bit-identical to
     :class:`LocalBank`."""
 
-    def __init__(self, bank, N: int, npf: int, group=None):
+    def __init__(self, bank, N: int, npf: int, group=None, loopback: bool = False):
         import torch.distributed as dist
-        self.bank, self.N, self.group = bank, N, group
+        self.bank, self.N, self.group, self.loopback = bank, N, group, loopback
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.lo, self.hi = shard_bounds(N, self.world, self.rank)
         nb = max(self.hi - self.lo, 1)
@@ -189,7 +193,7 @@ class ShardedBank(LocalBank):
     def resample(self, nidx):
         import torch
         import torch.distributed as dist
-        plan = migration_plan(nidx, self.N, self.world, self.rank)
+        plan = migration_plan(nidx, self.N, self.world, self.rank, self.loopback)
         on_device = dist.get_backend(self.group) == "nccl"
         send = self.pop.export_rows(plan["send_rows"])  # a copy of the rows that leave, taken before anything moves
         if not on_device and send.is_cuda:

@@ -109,14 +109,18 @@ def _log(x: float) -> float:
 
 def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool, alpha: float, npf: int,
               n_props: int = 1, seed: int = 1, rng: Optional[np.random.Generator] = None, verbose: bool = True,
-              proposal_correction: bool = False, distributed: bool = False, group=None) -> ImportanceSample:
+              proposal_correction: bool = False, distributed=False, group=None) -> ImportanceSample:
     """SMC^2 over the theta-particles ``theta`` (K x N).  ``bank`` is a :class:`ParticleFilter` (or any
     object with ``alloc_population``, ``partial_log_likelihood``, ``n_obs``, ``desc.obs_id``).
 
     ``proposal_correction`` (not in the reference): with independent proposals the reference accepts with
     ``exp(aw_f - aw[p])`` alone (src/hmm_ibis.jl:104), which leaves out ``q(theta)/q(theta_f)`` and biases
     the sample towards the proposal mean (its own test value of -ln evidence is 19.98 where the exact one is
-    20.1676).  ``False`` reproduces the reference; ``True`` adds the missing ratio."""
+    20.1676).  ``False`` reproduces the reference; ``True`` adds the missing ratio.
+
+    ``distributed``: ``True`` shards the theta-particles over the process group (:class:`parallel.ShardedBank`);
+    ``"loopback"`` additionally sends populations whose ancestor is local through the collective (test hook: the
+    all-to-all then carries data even with one rank)."""
     start = time.perf_counter_ns()
     rng = rng or np.random.default_rng(seed)
     theta = np.array(theta, dtype=np.float64, order="C")
@@ -131,7 +135,7 @@ def run_pibis(bank, prior, theta: np.ndarray, ess_rs_crit: float, ind_prop: bool
     if getattr(bank, "ess_frac", 0.0) > 0.0:
         # theta-level copies (gather / take) move states only, not the log-weights an ESS-adaptive filter carries
         raise ValueError("run_pibis needs a filter that resamples at every observation (ess_adaptive=False)")
-    sb = ShardedBank(bank, N, npf, group) if distributed else LocalBank(bank, N, npf)
+    sb = ShardedBank(bank, N, npf, group, loopback=(distributed == "loopback")) if distributed else LocalBank(bank, N, npf)
     try:
         mu, cv = np.zeros(K), np.zeros((K, K))
         k_log = [0, 0]

@@ -2,6 +2,7 @@
 all-gather of the log-likelihood vector.  The per-rank evaluator is the ORACLE here (tests may use
 it; on a GPU box the evaluator is ParticleFilter.loglik) -- what is under test is the sharding,
 the global segment index in the RNG key, and the collective."""
+import json
 import os
 import socket
 
@@ -185,3 +186,74 @@ def test_distributed_pmmh_equals_single_process(tmp_path, dp, orc):
                        prior, init, steps=60, adapt_period=30, seed=5, verbose=False)
     for r in range(2):
         assert np.array_equal(np.load(tmp_path / f"pmmh_rank{r}.npy"), ref.samples.theta)
+
+
+def _bench_leg_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import dpomp_amd as dp
+    from helpers import OracleBank
+    from oracle import oracle as orc
+    leg = bench.smc2_config4(dp, lambda model, y: OracleBank(dp, orc, model, y), 24, 48, distributed=True, reps=1)
+    with open(os.path.join(out_dir, f"leg_rank{rank}.json"), "w") as f:
+        json.dump(leg, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_smc2_leg_gives_the_same_evidence_for_every_number_of_ranks(tmp_path, dp, orc):
+    """bench.py's SMC^2 leg (BASELINE configuration 4: SEIR, theta-particles sharded over the ranks) at small size with
+    the oracle as the filter bank: two gloo ranks reproduce the single-process evidence bit for bit, and populations
+    really travel between them."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    from helpers import OracleBank
+    mp.spawn(_bench_leg_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = bench.smc2_config4(dp, lambda model, y: OracleBank(dp, orc, model, y), 24, 48, distributed=False, reps=1)
+    assert ref["n_resample"] >= 1 and np.all(np.isfinite(ref["minus_ln_evidence"]))
+    received = 0
+    for r in range(2):
+        got = json.load(open(tmp_path / f"leg_rank{r}.json"))
+        assert got["minus_ln_evidence"] == ref["minus_ln_evidence"] and got["posterior_mean"] == ref["posterior_mean"]
+        assert got["n_resample"] == ref["n_resample"] and got["block"] == 12
+        received += got["rows_received"]
+    assert received > 0
+
+
+def test_migration_plan_loopback_sends_local_ancestors_through_the_collective():
+    """The test hook behind the nccl world-1 GPU test: with loopback a rank's own populations also travel through the
+    all-to-all (send to self), and the plan still reconstructs pop[nidx]."""
+    from dpomp_amd.parallel import migration_plan
+    rng = np.random.default_rng(3)
+    N = 23
+    nidx = np.sort(rng.integers(0, N, N))
+    bank = np.arange(N) * 10
+    plan = migration_plan(nidx, N, 1, 0, loopback=True)
+    assert plan["send_counts"].tolist() == [len(np.unique(nidx))] == plan["recv_counts"].tolist()
+    assert len(plan["remote_slots"]) == N and np.array_equal(plan["local_anc"], np.arange(N))
+    recv = bank[plan["send_rows"]]
+    new = bank[plan["local_anc"]].copy()
+    new[plan["remote_slots"]] = recv[plan["remote_pick"]]
+    assert np.array_equal(new, bank[nidx])
+    for world in (2, 3):   # and with several ranks: every rank's block, self included, arrives through the buffers
+        from dpomp_amd.parallel import shard_bounds
+        plans = [migration_plan(nidx, N, world, r, loopback=True) for r in range(world)]
+        for r, p in enumerate(plans):
+            lo, hi = shard_bounds(N, world, r)
+            recv = []
+            for q in range(world):
+                qlo = shard_bounds(N, world, q)[0]
+                off = plans[q]["send_counts"][:r].sum()
+                rows = plans[q]["send_rows"][off:off + plans[q]["send_counts"][r]]
+                assert len(rows) == p["recv_counts"][q]
+                recv.extend(bank[qlo + rows])
+            recv = np.array(recv, dtype=np.int64)
+            new = bank[lo:hi][p["local_anc"]].copy()
+            new[p["remote_slots"]] = recv[p["remote_pick"]]
+            assert np.array_equal(new, bank[nidx[lo:hi]])

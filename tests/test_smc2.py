@@ -131,6 +131,13 @@ def test_sharded_bank_on_gpu_matches_local_bank(dp, pooley):
                          distributed=True)
         assert a.n_resample >= 1
         assert np.array_equal(a.bme, b.bme) and np.array_equal(a.theta, b.theta) and np.array_equal(a.weight, b.weight)
+        assert b.migration["rows_received"] == 0   # one rank: every ancestor is local, the all-to-all carries nothing
+        # loopback: the rank sends the populations its block descends from TO ITSELF through the collective, so
+        # all_to_all_single runs on the GPU over RCCL with non-zero split sizes on device tensors
+        c = dp.run_pibis(pf, prior, theta0, 0.3, True, 1.002, 256, seed=9, rng=np.random.default_rng(11), verbose=False,
+                         distributed="loopback")
+        assert c.migration["rows_received"] > 0
+        assert np.array_equal(a.bme, c.bme) and np.array_equal(a.theta, c.theta) and np.array_equal(a.weight, c.weight)
         # the view really aliases library memory
         pop = pf.alloc_population(2, 300)
         pf.partial_log_likelihood(pop, theta0[:, :2], 1, 2, seed=3)

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Where a filter call's time goes on the single-GPU shapes of the benchmark configurations (Pooley SIS 2^20, SEIR 4 x 2^18,
 SEIR 64 x 2^16, Lotka-Volterra 2^20, SIS 4000 x 200): wall time per call without
-profiling, then per-kernel average durations (HIP events carrying each kernel's own begin and end) and their sum.
+profiling, then per-kernel average durations (HIP events carrying each kernel's own begin and end) and their sum, and
+the propagation kernel's event rate against the VALU-issue ceiling of the model's event loop (valu_frac; ceilings from
+the ISA of the build: tools/isa_loop_count.py -> profiles/*/valu_ceilings.json).
 Usage: python tools/config_profile.py [reps]   -> JSON on stdout."""
 import json
+import os
 import sys
 import time
 
@@ -13,6 +16,23 @@ sys.path.insert(0, ".")
 import dpomp_amd as dp  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+
+
+def ceilings():
+    """{family: (VALU instructions per event, events/s ceiling)} of the compaction kernel, latest committed profile."""
+    out = {}
+    root = "profiles"
+    for d in sorted(os.listdir(root)):
+        f = os.path.join(root, d, "valu_ceilings.json")
+        if os.path.exists(f):
+            for label, v in json.load(open(f))["kernels"].items():
+                if "k_propagate_c" in label and "ceiling_events_per_s" in v:
+                    out[label.split(" ")[0]] = (v["valu"], v["ceiling_events_per_s"])
+    return out
+
+
+CEIL = ceilings()
+FAMILY = {"config2": "sis", "config3": "seir", "config4": "seir", "config5": "lotka", "smc2": "sis"}
 POOLEY = [(20.0, [0, 18]), (40.0, [0, 65]), (60.0, [0, 70]), (80.0, [0, 66]), (100.0, [0, 67])]
 rng = np.random.default_rng(1)
 th64 = np.stack([rng.uniform(0.003, 0.008, 64), rng.uniform(0.1, 0.3, 64), rng.uniform(0.05, 0.2, 64)])
@@ -46,5 +66,10 @@ for name, model, y, theta, P in CONFIGS:
     out[name] = {"ms_per_call": round(wall * 1e3, 4), "particle_steps_per_s": B * P * T / wall,
                  "kernel_us_per_call": round(sum(v["us_per_call"] for v in ks.values()), 1), "kernels": ks,
                  "events_per_call": pf.last_event_count(), "lane_utilisation": [round(float(u), 3) for u in pf.lane_utilisation()]}
+    fam = FAMILY[name.split("_")[0]]
+    if fam in CEIL and "k_propagate" in ks:
+        rate = pf.last_event_count() / (ks["k_propagate"]["us_per_call"] * 1e-6)
+        out[name]["propagate"] = {"events_per_s": float(f"{rate:.4g}"), "valu_instructions_per_event": CEIL[fam][0],
+                                  "valu_ceiling_events_per_s": float(f"{CEIL[fam][1]:.4g}"), "valu_frac": round(rate / CEIL[fam][1], 3)}
     pf.close()
 print(json.dumps(out, indent=1))

@@ -28,9 +28,10 @@ TRANS = {"v_rcp_f64", "v_sqrt_f64", "v_rsq_f64"}
 
 # kernel (mangled-name fragment) per BASELINE workload
 KERNELS = {
-    "sis (configs 1, 2; k_propagate_c<RSir<2>,32>)": "k_propagate_cINS_4RSirILi2ELb0EEELi32EE",
-    "seir (configs 3, 4; k_propagate_c<RSeir<4>,32>)": "k_propagate_cINS_5RSeirILi4ELb0EEELi32EE",
-    "lotka (config 5; k_propagate_c<RLotka,32>)": "k_propagate_cINS_6RLotkaELi32EE",
+    "sis (configs 1, 2; k_propagate_c<RSir<2>,32>)": "k_propagate_cINS_4RSirILi2ELb0EEELi32ELi0EE",
+    "seir (configs 3, 4; k_propagate_c<RSeir<4>,32>)": "k_propagate_cINS_5RSeirILi4ELb0EEELi32ELi0EE",
+    "lotka (config 5; k_propagate_c<RLotka,32>)": "k_propagate_cINS_6RLotkaELi32ELi0EE",
+    "sis-flat (filters laid end to end; k_propagate_c<RSir<2>,32,kModeFlat>)": "k_propagate_cINS_4RSirILi2ELb0EEELi32ELi1EE",
     "sis static schedule (k_propagate<RSir<2>>)": "k_propagateINS_4RSirILi2ELb0EEEE",
     "seir static schedule (k_propagate<RSeir<4>>)": "k_propagateINS_5RSeirILi4ELb0EEEE",
     "lotka static schedule (k_propagate<RLotka>)": "k_propagateINS_6RLotkaEEE",
