@@ -11,11 +11,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DPOMP_HIP_LIB") or os.path.join(HERE, "libdpomp_hip.so")  # (override: experiments, other installs)
 
-ABI_VERSION = 1
-MAX_STATES = 8
-MAX_EVENTS = 8
-MAX_PARAMS = 8
-MAX_FACTORS = 2
+ABI_VERSION = 2
+MAX_STATES = 32
+MAX_EVENTS = 32
+MAX_PARAMS = 32
+MAX_FACTORS = 4
+COMPILED_MAX = 8  # S, E, K up to which compiled-in evaluators exist; larger models are compiled at create time (hipRTC)
+FLAG_TABLE_INTERPRET, FLAG_TABLE_COMPILE = 1, 2
 
 OK = 0
 EINVAL, EDEVICE, ENOMEM, ESTATE = -1, -2, -3, -4
@@ -72,6 +74,8 @@ class ModelDescC(C.Structure):
         ("obs_id", C.POINTER(C.c_int64)),
         ("obs_value", C.POINTER(C.c_int64)),
         ("max_events_per_interval", C.c_int64),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -163,6 +163,7 @@ struct dpomp_handle {
     std::vector<long long> ysum;
     PropSet prop{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool prop_is_generic = false;
+    bool big = false;  // more than 8 states / events / parameters or more than 2 factors per rate: run-time compiled evaluator only
     // run-time compiled rate evaluator (dpomp_create_with_source)
     bool rtc = false;
     hipModule_t rtc_module = nullptr;
@@ -345,6 +346,16 @@ void collect_timings(dpomp_handle* h) {
     h->events_used = 0;
 }
 
+// A model beyond what the compiled-in evaluators (and DevModel's fixed arrays) hold: it runs on an evaluator generated
+// for its size at create time.
+bool model_is_big(const dpomp_model_desc* d) {
+    if (d->n_states > DPOMP_COMPILED_MAX || d->n_events > DPOMP_COMPILED_MAX || d->n_params > DPOMP_COMPILED_MAX) return true;
+    if (d->builtin_id != DPOMP_BUILTIN_USER)
+        for (int e = 0; e < d->n_events; ++e)
+            if (d->rate[e].n_factors > 2) return true;
+    return false;
+}
+
 int validate_desc(const dpomp_model_desc* d) {
     if (!d) return fail(nullptr, DPOMP_EINVAL, "descriptor is NULL");
     if (d->abi_version != DPOMP_ABI_VERSION)
@@ -360,7 +371,10 @@ int validate_desc(const dpomp_model_desc* d) {
     if (d->obs.kind == DPOMP_OBS_USER && d->builtin_id != DPOMP_BUILTIN_USER)
         return fail(nullptr, DPOMP_EINVAL, "a user observation model needs a run-time compiled model (DPOMP_BUILTIN_USER + dpomp_create_with_source)");
     if (d->obs.kind == DPOMP_OBS_GAUSSIAN && !(d->obs.sigma > 0.0)) return fail(nullptr, DPOMP_EINVAL, "obs.sigma must be positive");
-    if (d->obs.state_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "obs.state_mask names a state >= n_states");
+    if (d->n_states < 32 && (d->obs.state_mask >> d->n_states)) return fail(nullptr, DPOMP_EINVAL, "obs.state_mask names a state >= n_states");
+    if (d->flags & ~(DPOMP_FLAG_TABLE_INTERPRET | DPOMP_FLAG_TABLE_COMPILE)) return fail(nullptr, DPOMP_EINVAL, "unknown flags 0x%x", d->flags);
+    if ((d->flags & DPOMP_FLAG_TABLE_INTERPRET) && (d->flags & DPOMP_FLAG_TABLE_COMPILE))
+        return fail(nullptr, DPOMP_EINVAL, "flags ask for both an interpreted and a compiled rate table");
     if (d->n_obs_values < 32 && (d->obs.value_mask >> d->n_obs_values)) return fail(nullptr, DPOMP_EINVAL, "obs.value_mask names a value column >= n_obs_values");
     for (int s = 0; s < d->n_states; ++s)
         if (d->initial_condition[s] < 0 || d->initial_condition[s] >= ((int64_t)1 << 30))
@@ -374,8 +388,8 @@ int validate_desc(const dpomp_model_desc* d) {
         if (t.form != DPOMP_RATE_LEFT && t.form != DPOMP_RATE_RATIO) return fail(nullptr, DPOMP_EINVAL, "rate[%d].form unknown", e);
         if (t.n_factors < 0 || t.n_factors > DPOMP_MAX_FACTORS) return fail(nullptr, DPOMP_EINVAL, "rate[%d].n_factors out of range", e);
         for (int f = 0; f < t.n_factors; ++f)
-            if (t.factor_mask[f] == 0 || (t.factor_mask[f] >> d->n_states)) return fail(nullptr, DPOMP_EINVAL, "rate[%d].factor_mask[%d] invalid", e, f);
-        if (t.denom_mask >> d->n_states) return fail(nullptr, DPOMP_EINVAL, "rate[%d].denom_mask invalid", e);
+            if (t.factor_mask[f] == 0 || (d->n_states < 32 && (t.factor_mask[f] >> d->n_states))) return fail(nullptr, DPOMP_EINVAL, "rate[%d].factor_mask[%d] invalid", e, f);
+        if (d->n_states < 32 && (t.denom_mask >> d->n_states)) return fail(nullptr, DPOMP_EINVAL, "rate[%d].denom_mask invalid", e);
     }
     for (int t = 1; t < d->n_obs; ++t)
         if (d->obs_time[t] < d->obs_time[t - 1]) return fail(nullptr, DPOMP_EINVAL, "obs_time must be non-decreasing");
@@ -683,6 +697,7 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
     // lane_util = -1 (not measured yet) -> compaction.
     // (force_rpl 33 = the compaction schedule with the end-to-end layout of small filters forced on: tests, experiments)
     auto pick_variant = [&](int k) {
+        if (h->big) return 1;  // (the only multi-kernel schedule built for models beyond 8 states / events)
         if (h->force_rpl) return h->force_rpl == 33 ? 32 : h->force_rpl;
         return (B * ((p->P + 63) / 64) >= kCompactionMinWaves && h->lane_util[k] < kCompactionBelowUtil) ? kDefaultPropVariant : 1;
     };
@@ -941,11 +956,12 @@ RtcApi* rtc_api() {  // loaded on first use only: the library itself does not de
 }
 
 constexpr int kRtcKernels = 8;
-const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>",       "dpomp::k_propagate_c<dpomp::RUser, 32>",
-                                            "dpomp::k_simulate_rec<dpomp::RUser>",    "dpomp::k_filter_small<dpomp::RUser>",
+const char* const kRtcNames[kRtcKernels] = {"dpomp::k_propagate<dpomp::RUser>",       "dpomp::k_simulate_rec<dpomp::RUser>",
+                                            "dpomp::k_filter_small<dpomp::RUser>",    "dpomp::k_propagate_c<dpomp::RUser, 32>",
                                             "dpomp::k_propagate_q<dpomp::RUser, 2>",  "dpomp::k_propagate_q<dpomp::RUser, 4>",
                                             "dpomp::k_propagate_c<dpomp::RUser, 16>",
                                             "dpomp::k_propagate_c<dpomp::RUser, 32, dpomp::kModeFlat>"};
+constexpr int kRtcKernelsBig = 3;  // the leading entries: what a model beyond 8 states / events is built with
 const char* const kRtcOptions[] = {"--offload-arch=gfx950", "-ffp-contract=off", "-O3", "-std=c++17",
                                    "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                                    "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"};  // as the library itself is built
@@ -997,7 +1013,7 @@ bool cache_file_read(const std::string& file, RtcBinary& out) {
     bool ok = false;
     char magic[8];
     uint32_t n = 0;
-    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT3", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT4", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
         ok = true;
         for (int i = 0; ok && i < kRtcKernels; ++i) {
             uint32_t len = 0;
@@ -1026,7 +1042,7 @@ void cache_file_write(const std::string& dir, const std::string& file, const Rtc
     FILE* f = fopen(tmpname.c_str(), "wb");
     if (!f) return;
     const uint32_t n = kRtcKernels;
-    bool ok = fwrite("DPOMPRT3", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
+    bool ok = fwrite("DPOMPRT4", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
     for (int i = 0; ok && i < kRtcKernels; ++i) {
         const uint32_t len = (uint32_t)b.lowered[i].size();
         ok = fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[i].data(), 1, len, f) == len;
@@ -1044,20 +1060,39 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
     char head[512];
     snprintf(head, sizeof head, "#include \"dpomp_kernels.h\"\nnamespace dpomp {\n#line 1 \"rate_source\"\n");
     const bool user_obs = d->obs.kind == DPOMP_OBS_USER;
+    const bool big = model_is_big(d);
     char tail[1536];
     snprintf(tail, sizeof tail,
              "\nstruct RUser : RBase<%d, %d> {\n  static constexpr bool kUserObs = %s;\n"
              "  static __device__ __forceinline__ void rates(const DevModel&, const double* th, "
-             "const int (&x)[%d], double (&r)[%d]) { dpomp_user_rates(th, x, r); }\n%s};\n}  // namespace dpomp\n",
+             "const int (&x)[%d], double (&r)[%d]) { dpomp_user_rates(th, x, r); }\n%s",
              d->n_states, d->n_events, user_obs ? "true" : "false", d->n_states, d->n_events,
              user_obs ? "  static __device__ __forceinline__ double user_obs(const double* th, const int* x, const long long* y, int ny) "
                         "{ return dpomp_user_obs(th, x, y, ny); }\n"
                       : "");
-    const std::string src = std::string(head) + rate_source + tail;
+    std::string consts;
+    if (big) {  // initial condition and transition rows as constants of the evaluator (they do not fit DevModel)
+        consts += "  static constexpr bool kBig = true;\n  static __device__ __forceinline__ int x0(int s) {\n    switch (s) {\n";
+        for (int i = 0; i < d->n_states; ++i)
+            consts += "      case " + std::to_string(i) + ": return " + std::to_string((long long)d->initial_condition[i]) + ";\n";
+        consts += "    }\n    return 0;\n  }\n";
+        consts += "  static __device__ __forceinline__ void apply_event(int e, int (&x)[" + std::to_string(d->n_states) + "]) {\n    switch (e) {\n";
+        for (int e = 0; e < d->n_events; ++e) {
+            consts += "      case " + std::to_string(e) + ":";
+            for (int i = 0; i < d->n_states; ++i)
+                if (d->transition[e][i]) consts += " x[" + std::to_string(i) + "] += " + std::to_string(d->transition[e][i]) + ";";
+            consts += " break;\n";
+        }
+        consts += "    }\n  }\n";
+    }
+    const std::string src = std::string(head) + rate_source + tail + consts + "};\n}  // namespace dpomp\n";
+    // a big model runs the one-particle-per-lane kernel, the whole-filter kernel and the simulator; the compaction and
+    // LDS-queue schedules move contexts through fixed 32-byte LDS records and are built for small models only
+    const int n_names = big ? kRtcKernelsBig : kRtcKernels;
 
     std::string keytext = src;
     for (const char* o : kRtcOptions) keytext += std::string("\x01") + o;
-    for (const char* n : kRtcNames) keytext += std::string("\x02") + n;
+    for (int i = 0; i < n_names; ++i) keytext += std::string("\x02") + kRtcNames[i];
     int rt_version = 0;
     (void)hipRuntimeGetVersion(&rt_version);
     keytext += "\x03" + std::to_string(rt_version) + "\x03" + kSrcKernels + "\x03" + kSrcNumerics + "\x03" + kSrcLogTable;
@@ -1092,7 +1127,7 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
         log = "hiprtcCreateProgram failed";
         return DPOMP_EDEVICE;
     }
-    for (const char* n : kRtcNames) api->add_name(prog, n);
+    for (int i = 0; i < n_names; ++i) api->add_name(prog, kRtcNames[i]);
     const hiprtcResult r = api->compile(prog, kRtcOptionCount, kRtcOptions);
     size_t ls = 0;
     if (api->log_size && api->log_size(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
@@ -1106,7 +1141,8 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
     } else {
         for (int i = 0; i < kRtcKernels; ++i) {
             const char* ln = nullptr;
-            if (api->lowered(prog, kRtcNames[i], &ln) != HIPRTC_SUCCESS || !ln) rc = DPOMP_EDEVICE;
+            if (i >= n_names) bin.lowered[i] = "-";  // (not built for this model)
+            else if (api->lowered(prog, kRtcNames[i], &ln) != HIPRTC_SUCCESS || !ln) rc = DPOMP_EDEVICE;
             else bin.lowered[i] = ln;
         }
         size_t cs = 0;
@@ -1129,9 +1165,10 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
 // Loads a compiled model into the handle (module + the seven kernels).
 int rtc_load(dpomp_handle* h, const RtcBinary& bin, std::string& why) {
     hipError_t me = hipModuleLoadData(&h->rtc_module, bin.code.data());
-    hipFunction_t* fns[kRtcKernels] = {&h->rtc_prop1, &h->rtc_propc, &h->rtc_sim, &h->rtc_small, &h->rtc_q2, &h->rtc_q4, &h->rtc_c16,
+    hipFunction_t* fns[kRtcKernels] = {&h->rtc_prop1, &h->rtc_sim, &h->rtc_small, &h->rtc_propc, &h->rtc_q2, &h->rtc_q4, &h->rtc_c16,
                                        &h->rtc_c32_flat};
-    for (int i = 0; me == hipSuccess && i < kRtcKernels; ++i) me = hipModuleGetFunction(fns[i], h->rtc_module, bin.lowered[i].c_str());
+    for (int i = 0; me == hipSuccess && i < kRtcKernels; ++i)
+        if (bin.lowered[i] != "-") me = hipModuleGetFunction(fns[i], h->rtc_module, bin.lowered[i].c_str());
     if (me != hipSuccess) {
         why = hipGetErrorString(me);
         if (h->rtc_module) (void)hipModuleUnload(h->rtc_module);
@@ -1158,7 +1195,7 @@ std::string rate_table_source(const dpomp_model_desc* d) {
         const std::string th = "theta[" + std::to_string(t.theta_index) + "]", re = "r[" + std::to_string(e) + "]";
         if (t.form == DPOMP_RATE_LEFT) {
             s += "    { double v = " + th + ";";
-            for (int f = 0; f < t.n_factors; ++f) s += " v = v * (double)" + msum(t.factor_mask[f]) + ";";
+            for (int f = 0; f < t.n_factors; ++f) s += " v = v * (double)" + msum(t.factor_mask[f]) + ";";  // (any number of factors)
             if (t.denom_mask) s += " v = v / (double)" + msum(t.denom_mask) + ";";
             s += " " + re + " = v; }\n";
         } else {
@@ -1172,7 +1209,9 @@ std::string rate_table_source(const dpomp_model_desc* d) {
     return s + "}\n";
 }
 
-bool generic_jit_enabled() {
+bool generic_jit_enabled(const dpomp_model_desc* d) {
+    if (d->flags & DPOMP_FLAG_TABLE_INTERPRET) return false;
+    if (d->flags & DPOMP_FLAG_TABLE_COMPILE) return true;
     if (g_generic_jit >= 0) return g_generic_jit != 0;
     const char* env = getenv("DPOMP_GENERIC_JIT");
     return !(env && !strcmp(env, "0"));
@@ -1205,7 +1244,7 @@ int dpomp_device_count(void) {
     return n;
 }
 
-const char* dpomp_version(void) { return "dpomp-hip 0.1 (gfx950, abi 1)"; }
+const char* dpomp_version(void) { return "dpomp-hip 0.2 (gfx950, abi 2)"; }
 
 const char* dpomp_last_global_error(void) { return g_global_error.c_str(); }
 
@@ -1226,7 +1265,12 @@ int dpomp_check_rate_source(const dpomp_model_desc* d, const char* rate_source, 
     if (log && log_size > 0) log[0] = 0;
     int rc = validate_desc(d);
     if (rc != DPOMP_OK) return rc;
-    if (!rate_source) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
+    std::string table;  // rate_source == NULL: the source the descriptor's rate table is turned into at create time
+    if (!rate_source) {
+        if (d->builtin_id == DPOMP_BUILTIN_USER) return fail(nullptr, DPOMP_EINVAL, "rate_source is NULL");
+        table = rate_table_source(d);
+        rate_source = table.c_str();
+    }
     RtcBinary bin;
     std::string text;
     rc = rtc_compile(d, rate_source, bin, text);
@@ -1324,9 +1368,10 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     const double sigma = d->obs.kind == DPOMP_OBS_GAUSSIAN ? d->obs.sigma : 1.0;
     m.obs_tmp1 = std::log(1.0 / (std::sqrt(2.0 * M_PI) * sigma));  // hmm_examples.jl:61
     m.obs_tmp2 = 2.0 * sigma * sigma;                              // :62
-    for (int ev = 0; ev < 8; ++ev) {
+    h->big = model_is_big(d);
+    for (int ev = 0; ev < 8; ++ev) {  // (a big model's rows, rate terms and initial condition live in its generated evaluator)
         uint64_t w = 0;
-        if (ev < d->n_events)
+        if (ev < d->n_events && !h->big)
             for (int s = 0; s < d->n_states; ++s) w |= (uint64_t)(uint8_t)(int8_t)d->transition[ev][s] << (8 * s);
         m.trans_packed[ev] = w;
         const dpomp_rate_term& t = d->rate[ev < d->n_events ? ev : 0];
@@ -1334,7 +1379,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
         m.x0[ev] = ev < d->n_states ? (int32_t)d->initial_condition[ev] : 0;
     }
     for (const PropEntry& pe : kPropTable)
-        if (pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
+        if (!h->big && pe.builtin == d->builtin_id && pe.S == d->n_states && pe.E == d->n_events) h->prop = pe.set;
     h->evaluator = h->prop.fn1 ? DPOMP_EVALUATOR_BUILTIN : DPOMP_EVALUATOR_TABLE;
     if (rate_source) {
         RtcBinary bin;
@@ -1351,10 +1396,21 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
             return rc;
         }
         h->evaluator = DPOMP_EVALUATOR_SOURCE;
+    } else if (h->big) {  // a table too large for the interpreter: compiled, or not at all
+        RtcBinary bin;
+        std::string text;
+        if (d->flags & DPOMP_FLAG_TABLE_INTERPRET) text = "DPOMP_FLAG_TABLE_INTERPRET is set";
+        if (!text.empty() || rtc_compile(d, rate_table_source(d).c_str(), bin, text) != DPOMP_OK || rtc_load(h, bin, text) != DPOMP_OK) {
+            rc = fail(nullptr, DPOMP_EINVAL, "a model with more than %d states / events / parameters or more than 2 factors per rate has no "
+                      "compiled-in evaluator and must be compiled at create time (hipRTC): %.300s", DPOMP_COMPILED_MAX, text.c_str());
+            dpomp_destroy(h);
+            return rc;
+        }
+        h->evaluator = DPOMP_EVALUATOR_TABLE_COMPILED;
     } else if (!h->prop.fn1) {
         h->prop = generic_set(d->n_states, d->n_events);  // the table interpreter: always there as the fallback
         h->prop_is_generic = true;
-        if (generic_jit_enabled()) {  // a table model outside the catalogue: compile its table (cached), else interpret it
+        if (generic_jit_enabled(d)) {  // a table model outside the catalogue: compile its table (cached), else interpret it
             RtcBinary bin;
             std::string text;
             if (rtc_compile(d, rate_table_source(d).c_str(), bin, text) == DPOMP_OK && rtc_load(h, bin, text) == DPOMP_OK)
@@ -1436,6 +1492,8 @@ int dpomp_set_propagate_variant(dpomp_handle* h, int rpl) {
     if (!h) return DPOMP_EINVAL;
     if (rpl != 0 && rpl != 1 && rpl != 2 && rpl != 4 && rpl != 16 && rpl != 32 && rpl != 33)
         return fail(h, DPOMP_EINVAL, "propagate variant must be 0, 1, 2, 4, 16, 32 or 33");
+    if (h->big && rpl > 1)
+        return fail(h, DPOMP_EINVAL, "a model with more than %d states / events / parameters runs the one-particle-per-lane schedule only", DPOMP_COMPILED_MAX);
     h->force_rpl = rpl;
     return DPOMP_OK;
 }
@@ -1759,7 +1817,9 @@ int dpomp_set_profiling(dpomp_handle* h, int on) {
         HIPCHK(h, counted_malloc((void**)&scratch, (size_t)kTile * 64 * 4));
         for (int i = 0; i < n; ++i) {
             // filler: S rows of 8 tiles each (S <= 8 -> at most 64 tiles = the scratch size), 16-B aligned rows
-            hipLaunchKernelGGL(k_init, dim3(8, 1), dim3(kBlock), 0, h->stream, h->dm, scratch, (int64_t)kTile * 8);
+            DevModel filler = h->dm;
+            filler.S = std::min(filler.S, 8);  // (DevModel holds 8 components; the scratch block 8 rows)
+            hipLaunchKernelGGL(k_init, dim3(8, 1), dim3(kBlock), 0, h->stream, filler, scratch, (int64_t)kTile * 8);
             (void)hipEventRecord(ev[2 * i], h->stream);
             (void)hipEventRecord(ev[2 * i + 1], h->stream);
         }

@@ -122,6 +122,7 @@ struct RGeneric {  // interprets DevModel::rate (any model that fits the descrip
     static constexpr int S = S_, E = E_;
     static constexpr bool kGeneric = true;
     static constexpr bool kUserObs = false;
+    static constexpr bool kBig = false;
     static __device__ __forceinline__ int msum(uint32_t mask, const int (&x)[S]) {
         int s = 0;
 #pragma unroll
@@ -162,6 +163,10 @@ struct RBase {
     static constexpr int S = S_, E = E_;
     static constexpr bool kGeneric = false;
     static constexpr bool kUserObs = false;
+    // kBig (run-time compiled models only): more than 8 state components, events or parameters.  Such a model does
+    // not fit DevModel's fixed arrays: its initial condition and transition rows are constants of the generated
+    // evaluator (R::x0(s), R::apply_event(e, x)), and its parameters are read from memory, not held in registers.
+    static constexpr bool kBig = false;
     static __device__ __forceinline__ double total(const int (&x)[S_]) {
         int s = 0;
 #pragma unroll
@@ -240,9 +245,9 @@ struct ThetaRegs {
     double v[8];
     __device__ __forceinline__ ThetaRegs(const double* th, int K) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (!R::kGeneric && i < K) ? th[i] : 0.0;
+        for (int i = 0; i < 8; ++i) v[i] = (!R::kGeneric && !R::kBig && i < K) ? th[i] : 0.0;
     }
-    __device__ __forceinline__ const double* get(const double* th) const { return R::kGeneric ? th : v; }
+    __device__ __forceinline__ const double* get(const double* th) const { return (R::kGeneric || R::kBig) ? th : v; }
 };
 
 // Observation log-density of one particle: partial_gaussian_obs_model (hmm_examples.jl:59-67),
@@ -295,22 +300,33 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
     return v;
 }
 
+// Component s of the initial condition (pop[i,:] .= initial_condition, hmm_particle_filter.jl:42-44).
+template <class R>
+__device__ __forceinline__ int model_x0(const DevModel& m, int s) {
+    if constexpr (R::kBig) return R::x0(s);
+    else return m.x0[s];
+}
+
 // The packed transition rows, held in VGPRs for the whole event loop: selecting between two SGPR operands costs two
 // v_mov per event on top of the v_cndmask (one constant-bus read per VALU instruction on gfx9).  v[E-1] is the row
 // of the last real event (the inverse-CDF search falls through to it).
 template <class R>
 struct TransRows {
     using TW = typename cond_t<(R::S <= 4), uint32_t, uint64_t>::type;
-    TW v[R::E];
+    TW v[R::kBig ? 1 : R::E];  // (big models apply their transition rows as constants: R::apply_event)
     __device__ __forceinline__ TransRows(const DevModel& m, int e_real) {
+        if constexpr (R::kBig) {
+            v[0] = 0;
+            return;
+        }
 #pragma unroll
-        for (int i = 0; i < R::E; ++i) v[i] = (TW)m.trans_packed[i];
-        if (R::kGeneric) {  // padded evaluator: the last real row (selected with constant indices only)
+        for (int i = 0; i < (R::kBig ? 1 : R::E); ++i) v[i] = (TW)m.trans_packed[i];
+        if constexpr (R::kGeneric) {  // padded evaluator: the last real row (selected with constant indices only)
 #pragma unroll
             for (int i = 0; i < R::E - 1; ++i)
                 if (i == e_real - 1) v[R::E - 1] = (TW)m.trans_packed[i];
         }
-        if (!R::kGeneric) {
+        if constexpr (!R::kGeneric && !R::kBig) {
 #pragma unroll
             for (int i = 0; i < R::E; ++i) asm volatile("" : "+v"(v[i]));
         }
@@ -367,14 +383,22 @@ __device__ __forceinline__ bool gillespie_event(const DevModel& m, const TransRo
     time = time - (FAST ? div_in_range(now.lu, tot) : now.lu / tot);
     if (time > tmax) return false;
     const double etc = now.u2 * tot;
-    TW tw = rows.v[E - 1];
+    if constexpr (R::kBig) {  // the event's index by the same inverse-CDF chain, its row as constants of the evaluator
+        int ev = E - 1;
 #pragma unroll
-    for (int i = E - 2; i >= 0; --i) {
-        const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-        if (in_range && cum[i] > etc) tw = rows.v[i];
+        for (int i = E - 2; i >= 0; --i)
+            if (cum[i] > etc) ev = i;
+        R::apply_event(ev, x);
+    } else {
+        TW tw = rows.v[E - 1];
+#pragma unroll
+        for (int i = E - 2; i >= 0; --i) {
+            const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+            if (in_range && cum[i] > etc) tw = rows.v[i];
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
     }
-#pragma unroll
-    for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
     if constexpr (COUNT) return ++*n < cap;
     return true;
 }
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
 
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? a.m.x0[s] : ld[(int64_t)s * a.Pp + pj]) : 0;
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? model_x0<R>(a.m, s) : ld[(int64_t)s * a.Pp + pj]) : 0;
 
     double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
@@ -625,7 +649,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_q(PropArgs a) {
         if (idx < cnt) {
             const int p = base + idx;
 #pragma unroll
-            for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? (a.from_x0 ? a.m.x0[s] : st[(int64_t)s * a.Pp + p]) : 0;
+            for (int s = 0; s < S; ++s) s_x[s][idx] = (s < s_real) ? (a.from_x0 ? model_x0<R>(a.m, s) : st[(int64_t)s * a.Pp + p]) : 0;
             const StreamSeed r = stream_seed(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
             s_seed[idx] = make_uint4(r.w0, r.w1, r.w2, r.w3);
         }
@@ -866,7 +890,7 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
 
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? a.m.x0[s] : ld[(int64_t)s * a.Pp + pj]) : 0;
+    for (int s = 0; s < S; ++s) x[s] = (valid && s < s_real) ? (a.from_x0 ? model_x0<R>(a.m, s) : ld[(int64_t)s * a.Pp + pj]) : 0;
     double time = a.use_theta_t0 ? th[a.m.t0_index - 1] : a.t_prev;
     const double tmax = a.t_max;
     Stream rng = stream_init(a.seed, a.seg_base + (uint32_t)b, (uint32_t)p, a.obs_k, a.domain);
@@ -1142,7 +1166,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
     int x[S];
 #pragma unroll
     for (int s = 0; s < S; ++s)
-        x[s] = (!valid || s >= s_real) ? 0 : (a.ymin == 1 ? a.m.x0[s] : st[(int64_t)s * a.Pp + tid]);
+        x[s] = (!valid || s >= s_real) ? 0 : (a.ymin == 1 ? model_x0<R>(a.m, s) : st[(int64_t)s * a.Pp + tid]);
     double t_prev = (a.ymin == 1) ? (a.m.t0_index > 0 ? th[a.m.t0_index - 1] : 0.0) : a.obs_time[a.ymin - 2];
     const int cap = a.m.cap;
     double ll = 0.0;
@@ -1268,7 +1292,7 @@ __global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
     const TransRows<R> rows(a.m, e_real);
     int x[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) x[s] = (s < s_real) ? a.m.x0[s] : 0;
+    for (int s = 0; s < S; ++s) x[s] = (s < s_real) ? model_x0<R>(a.m, s) : 0;
     double time = a.m.t0_index > 0 ? a.theta[a.m.t0_index - 1] : 0.0;
     long long n = 0;
     bool overflow = false;
@@ -1285,18 +1309,25 @@ __global__ __launch_bounds__(kBlock) void k_simulate_rec(SimArgs a) {
             time = time - dlog(u01(stream_next(rng))) / tot;
             if (time > tmax) break;
             const double etc = u01(stream_next(rng)) * tot;
-            TW tw = (TW)a.m.trans_packed[e_real - 1];
             int ev = e_real - 1;
+            if constexpr (R::kBig) {
 #pragma unroll
-            for (int i = E - 2; i >= 0; --i) {
-                const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
-                if (in_range && cum[i] > etc) {
-                    tw = (TW)a.m.trans_packed[i];
-                    ev = i;
+                for (int i = E - 2; i >= 0; --i)
+                    if (cum[i] > etc) ev = i;
+                R::apply_event(ev, x);
+            } else {
+                TW tw = (TW)a.m.trans_packed[e_real - 1];
+#pragma unroll
+                for (int i = E - 2; i >= 0; --i) {
+                    const bool in_range = R::kGeneric ? (i < e_real - 1) : true;
+                    if (in_range && cum[i] > etc) {
+                        tw = (TW)a.m.trans_packed[i];
+                        ev = i;
+                    }
                 }
-            }
 #pragma unroll
-            for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+                for (int s = 0; s < S; ++s) x[s] += (int)(int8_t)(tw >> (8 * s));
+            }
             if (n >= a.max_events) {
                 overflow = true;
                 break;

@@ -11,9 +11,10 @@ import DiscretePOMP
 
 const LIB = get(ENV, "DPOMP_HIP_LIB", joinpath(@__DIR__, "..", "libdpomp_hip.so"))
 
-const MAX_STATES = 8
-const MAX_EVENTS = 8
-const MAX_FACTORS = 2
+const ABI_VERSION = 2       # DPOMP_ABI_VERSION
+const MAX_STATES = 32       # DPOMP_MAX_STATES (models beyond 8 states / events / parameters are compiled at create time)
+const MAX_EVENTS = 32
+const MAX_FACTORS = 4
 
 struct RateTermC            # dpomp_rate_term
     theta_index::Int32      # 0-based
@@ -48,6 +49,8 @@ struct ModelDescC           # dpomp_model_desc (field order and padding as in in
     obs_id::Ptr{Int64}
     obs_value::Ptr{Int64}
     max_events_per_interval::Int64
+    flags::Int32            # DPOMP_FLAG_*: 1 = interpret a rate table, 2 = compile it, 0 = the library's default
+    reserved::Int32
 end
 
 # catalogue name (DPOMPModel.model_name as stored by generate_model, src/hmm_examples.jl:171-204)
@@ -130,12 +133,12 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
     for e in 1:E, s in 1:S
         trans[(e - 1) * MAX_STATES + s] = model.m_transition[e, s]
     end
-    zero_term = RateTermC(0, 0, 0, (UInt32(0), UInt32(0)), UInt32(0))
-    desc = Ref(ModelDescC(1, S, E, K, freq_dep ? b_fd : b_dd, model.t0_index,
+    zero_term = RateTermC(0, 0, 0, ntuple(_ -> UInt32(0), MAX_FACTORS), UInt32(0))
+    desc = Ref(ModelDescC(ABI_VERSION, S, E, K, freq_dep ? b_fd : b_dd, model.t0_index,
                           pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
                           pad(terms, MAX_EVENTS, zero_term),
                           ObsModelC(1 #= DPOMP_OBS_GAUSSIAN =#, mask(seq), mask(seq), 0, obs_error),
-                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
+                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0, 0, 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve obs_time obs_id obs_value begin
         rc = ccall((:dpomp_create, LIB), Cint, (Ref{ModelDescC}, Cint, Ref{Ptr{Cvoid}}), desc, device, h)
@@ -168,11 +171,11 @@ function Filter(model::DiscretePOMP.DPOMPModel, y::Vector{DiscretePOMP.Observati
     for e in 1:E, s in 1:S
         trans[(e - 1) * MAX_STATES + s] = model.m_transition[e, s]
     end
-    zero_term = RateTermC(0, 0, 0, (UInt32(0), UInt32(0)), UInt32(0))
-    desc = Ref(ModelDescC(1, S, E, n_params, 100 #= DPOMP_BUILTIN_USER =#, model.t0_index,
+    zero_term = RateTermC(0, 0, 0, ntuple(_ -> UInt32(0), MAX_FACTORS), UInt32(0))
+    desc = Ref(ModelDescC(ABI_VERSION, S, E, n_params, 100 #= DPOMP_BUILTIN_USER =#, model.t0_index,
                           pad(Int64.(model.initial_condition), MAX_STATES, Int64(0)), Tuple(trans),
                           ntuple(_ -> zero_term, MAX_EVENTS), ObsModelC(user_obs ? 100 : 1, mask(seq), mask(seq), 0, obs_error),
-                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0))
+                          length(y), V, pointer(obs_time), pointer(obs_id), pointer(obs_value), 0, 0, 0))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve obs_time obs_id obs_value begin
         rc = ccall((:dpomp_create_with_source, LIB), Cint, (Ref{ModelDescC}, Cint, Cstring, Ref{Ptr{Cvoid}}),

@@ -370,7 +370,8 @@ def generate_custom_model(model_name: str, rate_function, initial_condition, m_t
 class ModelDescriptor:
     """Owns a ``dpomp_model_desc`` and the arrays it points to."""
 
-    def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], force_generic: bool = False):
+    def __init__(self, model: DPOMPModel, obs_data: Sequence[Observation], force_generic: bool = False,
+                 jit: "bool | None" = None):
         S, E = model.n_states, model.n_events
         if S > _abi.MAX_STATES or E > _abi.MAX_EVENTS:
             raise ValueError(f"model exceeds {_abi.MAX_STATES} states / {_abi.MAX_EVENTS} events")
@@ -433,6 +434,9 @@ class ModelDescriptor:
         d.obs_id = self.obs_id.ctypes.data_as(C.POINTER(C.c_int64))
         d.obs_value = self.obs_value.ctypes.data_as(C.POINTER(C.c_int64))
         d.max_events_per_interval = int(model.max_events_per_interval)
+        # a rate table outside the catalogue: compiled at create time (True), interpreted on the device (False), or the
+        # library's process-wide default (None) -- decided per model, in the descriptor
+        d.flags = 0 if jit is None else (_abi.FLAG_TABLE_COMPILE if jit else _abi.FLAG_TABLE_INTERPRET)
         self.c = d
 
     def byref(self):

@@ -146,18 +146,13 @@ class ParticleFilter:
         self._h = C.c_void_p()
         self.device = int(device)
         self.model = model
-        self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic)
+        self.desc = ModelDescriptor(model, obs_data, force_generic=force_generic, jit=jit)
         self.n_states, self.n_params, self.n_obs = self.desc.n_states, self.desc.n_params, self.desc.n_obs
         self.essc = essc  # accepted and unused, as in the reference (src/hmm_particle_filter.jl:63-68)
         # a rate table outside the catalogue is compiled at create time (cached; jit=False: interpret it on the device;
-        # None: the library default, on unless DPOMP_GENERIC_JIT=0)
-        if jit is not None:
-            self._lib.dpomp_set_generic_jit(1 if jit else 0)
-        try:
-            rc = self._create()
-        finally:
-            if jit is not None:
-                self._lib.dpomp_set_generic_jit(-1)
+        # None: the library default, on unless DPOMP_GENERIC_JIT=0) -- a flag of this model's descriptor, so the choice
+        # touches no process-wide state
+        rc = self._create()
         if rc != _abi.OK:
             self._h = C.c_void_p()
             raise DpompError(rc, self._lib.dpomp_last_global_error().decode())
@@ -373,14 +368,13 @@ class ParticleFilter:
 
 
 def check_rate_source(model: DPOMPModel, obs_data: Sequence[Observation]) -> str:
-    """Compile-only check of a :class:`RateSource` model (needs no GPU).  Returns the compiler log; raises
-    :class:`DpompError` with the diagnostics if the source does not compile."""
+    """Compile-only check (needs no GPU) of a :class:`RateSource` model, or of the evaluator a rate-table model is
+    turned into at create time.  Returns the compiler log; raises :class:`DpompError` with the diagnostics if the
+    source does not compile."""
     lib = _abi.load_library()
     desc = ModelDescriptor(model, obs_data)
-    if desc.rate_source is None:
-        raise TypeError("model.rate_function is not a RateSource")
     log = C.create_string_buffer(1 << 16)
-    rc = lib.dpomp_check_rate_source(desc.byref(), desc.rate_source.encode(), log, len(log))
+    rc = lib.dpomp_check_rate_source(desc.byref(), desc.rate_source.encode() if desc.rate_source is not None else None, log, len(log))
     if rc != _abi.OK:
         raise DpompError(rc, log.value.decode(errors="replace") or lib.dpomp_last_global_error().decode())
     return log.value.decode(errors="replace")

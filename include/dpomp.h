@@ -53,12 +53,23 @@
 extern "C" {
 #endif
 
-#define DPOMP_ABI_VERSION 1
+#define DPOMP_ABI_VERSION 2
 
-#define DPOMP_MAX_STATES 8   /* S: state components        */
-#define DPOMP_MAX_EVENTS 8   /* E: event types             */
-#define DPOMP_MAX_PARAMS 8   /* K: model parameters        */
-#define DPOMP_MAX_FACTORS 2  /* integer factors per rate   */
+/* Limits of the descriptor.  The reference's DPOMPModel has none (any closure, any size: hmm_structs.jl:107-116); here a
+ * model is data.  Models of up to DPOMP_COMPILED_MAX state components, events and parameters with at most two integer
+ * factors per rate run on evaluators that are compiled into the library (the catalogue, and a table interpreter as the
+ * fallback).  Anything larger -- up to the DPOMP_MAX_* below, e.g. an age-structured model with a dozen compartments --
+ * is compiled at create time (hipRTC: rate table or user source turned into an evaluator of exactly its size) and
+ * needs hipRTC to be available. */
+#define DPOMP_MAX_STATES 32  /* S: state components        */
+#define DPOMP_MAX_EVENTS 32  /* E: event types             */
+#define DPOMP_MAX_PARAMS 32  /* K: model parameters        */
+#define DPOMP_MAX_FACTORS 4  /* integer factors per rate   */
+#define DPOMP_COMPILED_MAX 8 /* S, E, K up to which compiled-in evaluators exist (with at most 2 factors per rate) */
+
+/* dpomp_model_desc.flags */
+#define DPOMP_FLAG_TABLE_INTERPRET 1 /* a rate table outside the catalogue: interpret it on the device (no hipRTC)  */
+#define DPOMP_FLAG_TABLE_COMPILE 2   /* ... compile it at create time, whatever the process-wide default says        */
 
 /* error codes */
 #define DPOMP_OK 0
@@ -138,6 +149,8 @@ typedef struct dpomp_model_desc {
     const int64_t* obs_value; /* [T*V] Observation.val, observation-major: obs_value[t*V + v] */
     int64_t max_events_per_interval; /* per particle and interval; <=0 selects the default (1<<22).
                                         The reference PF has no cap (hmm_particle_filter.jl:19-27). */
+    int32_t flags;        /* DPOMP_FLAG_*; 0 = the process-wide default (dpomp_set_generic_jit) */
+    int32_t reserved;
 } dpomp_model_desc;
 
 typedef struct dpomp_handle dpomp_handle;
@@ -163,7 +176,8 @@ int dpomp_create(const dpomp_model_desc* desc, int device, dpomp_handle** out);
  * hipRTC for gfx950 together with the library's kernels (-ffp-contract=off: results stay reproducible by the
  * same source compiled for the host).  desc->builtin_id must be DPOMP_BUILTIN_USER. */
 int dpomp_create_with_source(const dpomp_model_desc* desc, int device, const char* rate_source, dpomp_handle** out);
-/* Compile-only check of a rate source (needs no GPU); the compiler log is copied into log[log_size]. */
+/* Compile-only check of a rate source (needs no GPU); the compiler log is copied into log[log_size].  With
+ * rate_source == NULL the descriptor's rate table is checked: the evaluator dpomp_create would generate from it. */
 int dpomp_check_rate_source(const dpomp_model_desc* desc, const char* rate_source, char* log, int64_t log_size);
 /* How the handle evaluates rates: a model of the catalogue runs a compiled-in evaluator; a rate table outside the
  * catalogue is turned into source at dpomp_create and compiled with hipRTC like a user's rate source (same arithmetic
@@ -176,8 +190,9 @@ int dpomp_check_rate_source(const dpomp_model_desc* desc, const char* rate_sourc
 #define DPOMP_EVALUATOR_TABLE_COMPILED 3 /* rate table compiled at create time             */
 #define DPOMP_EVALUATOR_SOURCE 4         /* user rate source (dpomp_create_with_source)    */
 int dpomp_get_evaluator(const dpomp_handle* h);
-/* Process-wide switch for compiling rate tables: 1 on, 0 off (interpret), -1 default = on unless the environment has
- * DPOMP_GENERIC_JIT=0.  Applies to handles created afterwards. */
+/* Process-wide default for compiling rate tables: 1 on, 0 off (interpret), -1 = on unless the environment has
+ * DPOMP_GENERIC_JIT=0.  Applies to handles created afterwards whose descriptor does not decide for itself
+ * (dpomp_model_desc.flags: DPOMP_FLAG_TABLE_INTERPRET / DPOMP_FLAG_TABLE_COMPILE -- the per-model, thread-safe way). */
 int dpomp_set_generic_jit(int mode);
 void dpomp_destroy(dpomp_handle* h);
 const char* dpomp_last_error(const dpomp_handle* h);

@@ -17,7 +17,7 @@ int main(void) {
     static const double t[5] = {20, 40, 60, 80, 100};
     static const int64_t id[5] = {1, 1, 0, 1, 1}, val[10] = {0, 18, 0, 65, 0, 70, 0, 66, 0, 67};
     dpomp_model_desc d; memset(&d, 0, sizeof d);
-    d.abi_version = 1; d.n_states = 2; d.n_events = 2; d.n_params = 2;
+    d.abi_version = DPOMP_ABI_VERSION; d.n_states = 2; d.n_events = 2; d.n_params = 2;
     d.initial_condition[0] = 100; d.initial_condition[1] = 1;
     d.transition[0][0] = -1; d.transition[0][1] = 1; d.transition[1][0] = 1; d.transition[1][1] = -1;
     d.rate[0].n_factors = 2; d.rate[0].factor_mask[0] = 1; d.rate[0].factor_mask[1] = 2;

@@ -1,0 +1,28 @@
+#!/bin/bash
+# rocprofv3 evidence of round 3 (run on the GPU box from the repo root):  bash tools/collect_profiles_r03.sh gpurun_out/prof3
+#  bench passes      as tools/collect_profiles.sh (kernel trace + stats, FETCH_SIZE, WRITE_SIZE, SQ counters)
+#  hbm-scale passes  tools/hbm_scale_probe.py at working sets beyond the 256 MiB Infinity Cache
+#  interval passes   tools/interval_trace.py: kernel trace and SQ counters per observation interval of every
+#                    benchmark configuration (the propagation kernel against its VALU-issue ceiling, interval by interval)
+# Every pass is its own process under its own time limit; counters are never combined with sys/hip/hsa traces.
+set -e -o pipefail
+OUT=${1:-gpurun_out/prof3}
+REPO=$(pwd)
+cd /tmp && export TMPDIR=/tmp && cd "$REPO"
+mkdir -p "$OUT/hbm" "$OUT/interval"
+[ -n "$SKIP_BENCH" ] || bash tools/collect_profiles.sh "$OUT/bench"
+if [ -z "$SKIP_HBM" ]; then
+P="python3 tools/hbm_scale_probe.py 4 sis_16x2^20 seir_64x2^18 seir_64x2^18+incremental seir_64x2^16_config4_share seir_64x2^16_config4_share+incremental"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hbm/trace" -- $P > "$OUT/hbm/probe_under_rocprof.json" 2> "$OUT/hbm/trace.err"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/hbm/pmc_fetch" -- $P > /dev/null 2> "$OUT/hbm/pmc_fetch.err"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/hbm/pmc_write" -- $P > /dev/null 2> "$OUT/hbm/pmc_write.err"
+python3 tools/summarise_profiles.py "$OUT/hbm" "$OUT/hbm/summary"
+fi
+I="python3 tools/interval_trace.py run"
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/interval/trace" -- $I "$OUT/interval/plan.json" > "$OUT/interval/trace.log" 2>&1
+python3 tools/interval_trace.py parse "$OUT/interval/trace" "$OUT/interval/plan.json" > "$OUT/interval/interval_trace.json"
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/interval/pmc/sq1" -- $I "$OUT/interval/plan_sq.json" > "$OUT/interval/sq1.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/interval/pmc/sq2" -- $I "$OUT/interval/plan_sq.json" > "$OUT/interval/sq2.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$OUT/interval/pmc/sq3" -- $I "$OUT/interval/plan_sq.json" > "$OUT/interval/sq3.log" 2>&1
+python3 tools/interval_trace.py parse_pmc "$OUT/interval/pmc" "$OUT/interval/plan_sq.json" > "$OUT/interval/interval_sq_counters.json"
+echo "done: $OUT/bench/summary, $OUT/hbm/summary, $OUT/interval"

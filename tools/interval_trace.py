@@ -6,6 +6,10 @@ configurations.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/itrace -- python3 tools/interval_trace.py run gpurun_out/itrace_plan.json
     python3 tools/interval_trace.py parse gpurun_out/itrace gpurun_out/itrace_plan.json > profiles/r03/interval_trace.json
+
+SQ counters per interval (each --pmc pass a run of its own, directories <raw>/sq1, sq2, sq3 as tools/collect_profiles_r03.sh
+makes them):
+    python3 tools/interval_trace.py parse_pmc <raw> <plan.json> > profiles/r03/interval_sq_counters.json
 """
 import csv
 import glob
@@ -113,8 +117,56 @@ def parse(raw, plan_file):
     print(json.dumps(out, indent=1))
 
 
+def parse_pmc(raw, plan_file):
+    """Per configuration and interval: SQ counters of the propagation launch, averaged over the measured calls, with
+    the derived figures of tools/summarise_profiles.py (VALU busy fraction of the chip, lane utilisation of the issued
+    VALU instructions, VALU instructions per event and wave)."""
+    plan = json.load(open(plan_file))
+    per_pass = {}
+    for sub in sorted(os.listdir(raw)):
+        files = glob.glob(os.path.join(raw, sub, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        rows = {}
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            if "k_propagate" not in r["Kernel_Name"] and "k_filter_small" not in r["Kernel_Name"]:
+                continue
+            rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        per_pass[sub] = [rows[k] for k in sorted(rows)]
+    out = {}
+    for sub, disp in per_pass.items():
+        pos = 0
+        for c in plan["configs"]:
+            T = c["T"]
+            pos += plan["warm"] * T
+            acc = [dict() for _ in range(T)]
+            for i in range(plan["measured"]):
+                for k in range(T):
+                    for name, v in disp[pos].items():
+                        acc[k][name] = acc[k].get(name, 0.0) + v / plan["measured"]
+                    pos += 1
+            pos += T
+            o = out.setdefault(c["name"], {"events_per_interval": c["events"], "intervals": [dict() for _ in range(T)]})
+            for k in range(T):
+                o["intervals"][k].update(acc[k])
+        assert pos == len(disp), (sub, pos, len(disp))
+    for name, o in out.items():
+        for k, v in enumerate(o["intervals"]):
+            ev = o["events_per_interval"][k]
+            if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
+                v["lane_utilisation_issued"] = round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 3)
+            if v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE"):
+                v["valu_busy_frac"] = round(v["SQ_ACTIVE_INST_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+            if v.get("SQ_INSTS_VALU") and ev:
+                v["valu_instructions_per_event_lane"] = round(v["SQ_THREAD_CYCLES_VALU"] / 4.0 / ev, 1) if v.get("SQ_THREAD_CYCLES_VALU") else None
+                v["wave_valu_instructions_per_64_events"] = round(v["SQ_INSTS_VALU"] / (ev / 64.0), 1)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
+    elif sys.argv[1] == "parse_pmc":
+        parse_pmc(sys.argv[2], sys.argv[3])
     else:
         parse(sys.argv[2], sys.argv[3])

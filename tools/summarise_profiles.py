@@ -119,7 +119,9 @@ def main(raw, out):
     for k, v in sq.items():
         if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_THREAD_CYCLES_VALU"):
             v["lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"])
-        if v.get("GRBM_GUI_ACTIVE") and v.get("avg_duration_us_under_pmc"):
+        # (GRBM_GUI_ACTIVE spans the idle gaps around a dispatch: for launches of a few microseconds the quotient is not
+        # a clock, so it is only derived for dispatches of 50 us and more)
+        if v.get("GRBM_GUI_ACTIVE") and v.get("avg_duration_us_under_pmc", 0.0) >= 50.0:
             v["clock_GHz"] = v["GRBM_GUI_ACTIVE"] / 8.0 / (v["avg_duration_us_under_pmc"] * 1e3)   # summed over 8 XCDs
         if v.get("SQ_ACTIVE_INST_VALU") and v.get("GRBM_GUI_ACTIVE"):
             # SQ_ACTIVE_INST_VALU counts 4-cycle issue quads; 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
