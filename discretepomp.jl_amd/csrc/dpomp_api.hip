@@ -1002,9 +1002,18 @@ std::string cache_dir() {
     return std::string(home) + "/.cache/dpomp";
 }
 
-void make_dirs(const std::string& path) {
+// The cache holds GPU code objects that dpomp_create loads: the directory must belong to the caller and be writable
+// by nobody else, or another local user could plant a code object under the name a model hashes to.  Missing
+// directories are created private (0700); a directory that fails the check is not used (models are compiled afresh).
+bool cache_dir_is_private(const std::string& dir) {
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+bool make_private_dirs(const std::string& path) {
     for (size_t i = 1; i <= path.size(); ++i)
-        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+        if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), i == path.size() ? 0700 : 0755);
+    return cache_dir_is_private(path);
 }
 
 bool cache_file_read(const std::string& file, RtcBinary& out) {
@@ -1013,7 +1022,7 @@ bool cache_file_read(const std::string& file, RtcBinary& out) {
     bool ok = false;
     char magic[8];
     uint32_t n = 0;
-    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT4", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
+    if (fread(magic, 1, 8, f) == 8 && !memcmp(magic, "DPOMPRT5", 8) && fread(&n, 4, 1, f) == 1 && n == (uint32_t)kRtcKernels) {
         ok = true;
         for (int i = 0; ok && i < kRtcKernels; ++i) {
             uint32_t len = 0;
@@ -1024,10 +1033,13 @@ bool cache_file_read(const std::string& file, RtcBinary& out) {
             }
         }
         uint64_t cs = 0;
-        ok = ok && fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 30);
+        char sum[32];
+        ok = ok && fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < ((uint64_t)1 << 30) && fread(sum, 1, 32, f) == 32;
         if (ok) {
             out.code.resize((size_t)cs);
             ok = fread(out.code.data(), 1, (size_t)cs, f) == (size_t)cs && fgetc(f) == EOF;
+            // (a checksum of the code object: a truncated or altered file is recompiled, not loaded)
+            ok = ok && !memcmp(sum, hash_hex(std::string(out.code.data(), out.code.size())).c_str(), 32);
         }
     }
     fclose(f);
@@ -1035,20 +1047,21 @@ bool cache_file_read(const std::string& file, RtcBinary& out) {
 }
 
 void cache_file_write(const std::string& dir, const std::string& file, const RtcBinary& b) {
-    make_dirs(dir);
+    if (!make_private_dirs(dir)) return;
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%d.%p", (int)getpid(), (const void*)&b);
     const std::string tmpname = file + tmp;
     FILE* f = fopen(tmpname.c_str(), "wb");
     if (!f) return;
     const uint32_t n = kRtcKernels;
-    bool ok = fwrite("DPOMPRT4", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
+    bool ok = fwrite("DPOMPRT5", 1, 8, f) == 8 && fwrite(&n, 4, 1, f) == 1;
     for (int i = 0; ok && i < kRtcKernels; ++i) {
         const uint32_t len = (uint32_t)b.lowered[i].size();
         ok = fwrite(&len, 4, 1, f) == 1 && fwrite(b.lowered[i].data(), 1, len, f) == len;
     }
     const uint64_t cs = b.code.size();
-    ok = ok && fwrite(&cs, 8, 1, f) == 1 && fwrite(b.code.data(), 1, b.code.size(), f) == b.code.size();
+    const std::string sum = hash_hex(std::string(b.code.data(), b.code.size()));
+    ok = ok && fwrite(&cs, 8, 1, f) == 1 && fwrite(sum.data(), 1, 32, f) == 32 && fwrite(b.code.data(), 1, b.code.size(), f) == b.code.size();
     ok = (fclose(f) == 0) && ok;
     if (!ok || rename(tmpname.c_str(), file.c_str()) != 0) (void)remove(tmpname.c_str());
 }
@@ -1108,7 +1121,7 @@ int rtc_compile(const dpomp_model_desc* d, const char* rate_source, RtcBinary& b
             return DPOMP_OK;
         }
     }
-    if (!file.empty() && cache_file_read(file, bin)) {
+    if (!file.empty() && cache_dir_is_private(dir) && cache_file_read(file, bin)) {
         std::lock_guard<std::mutex> lock(g_rtc_cache_mutex);
         g_rtc_cache[key] = bin;
         if (from_cache) *from_cache = true;

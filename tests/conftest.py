@@ -15,7 +15,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # compiled path (ParticleFilter(..., jit=True): tests/test_table_jit.py); compiled models of a run are cached in a
 # directory of its own.
 os.environ.setdefault("DPOMP_GENERIC_JIT", "0")
-os.environ.setdefault("DPOMP_CACHE_DIR", os.path.join(__import__("tempfile").gettempdir(), f"dpomp_cache_{os.getuid()}"))
+if "DPOMP_CACHE_DIR" not in os.environ:  # a private directory of this run (the library refuses a cache it does not own)
+    import atexit
+    import shutil
+    import tempfile
+    os.environ["DPOMP_CACHE_DIR"] = tempfile.mkdtemp(prefix="dpomp_cache_")
+    atexit.register(shutil.rmtree, os.environ["DPOMP_CACHE_DIR"], ignore_errors=True)
 
 
 def pytest_configure(config):

@@ -185,3 +185,28 @@ def test_spec_mode_tracks_faithful_mode_with_t0_index_and_unweighted_rows(dp, or
         assert a.events == b.events and abs(a.ll - b.ll) < 1e-11
         assert a.per_obs_ll[1] == 0.0 and b.per_obs_ll[1] == 0.0
         assert int((a.ancestors != b.ancestors).sum()) <= 1
+
+
+def test_seir_evidence_table_is_reproducible_and_converged(dp):
+    """tests/golden/seir_evidence.json (made by tests/golden/make_seir_evidence.py: exact SEIR likelihood on a tensor
+    Gauss-Legendre grid over a uniform prior box): the two stored rules agree (quadrature converged to < 0.01 in
+    -ln evidence, 0.4 % in the posterior mean), the box holds the posterior mass, and a stored node is reproduced by the
+    forward algorithm today."""
+    import json
+    ev = json.load(open(os.path.join(GOLDEN, "seir_evidence.json")))
+    fine, coarse = ev["rules"]
+    assert fine["n"] == 12 and coarse["n"] == 9
+    assert abs(fine["neg_log_evidence"] - coarse["neg_log_evidence"]) < 0.01 and ev["quadrature_error_estimate"] < 0.01
+    assert np.allclose(fine["posterior_mean"], coarse["posterior_mean"], rtol=8e-3)
+    assert max(fine["edge_share"]) < 0.02 and fine["max_truncation"] < 1e-12
+    # weights of the rule reproduce the stored evidence from the stored log-likelihoods
+    x, w = np.polynomial.legendre.leggauss(12)
+    W = np.einsum("i,j,k->ijk", w / 2, w / 2, w / 2).reshape(-1)
+    ll = np.array(fine["ll"])
+    assert abs(-(ll.max() + np.log(np.sum(W * np.exp(ll - ll.max())))) - fine["neg_log_evidence"]) < 1e-12
+    # one node, recomputed: the node of the largest likelihood
+    i = int(ll.argmax())
+    a = [fine["axes"][0][i // 144], fine["axes"][1][(i // 12) % 12], fine["axes"][2][i % 12]]
+    y = dp.get_observations(os.path.join(GOLDEN, "seir_synthetic.csv"))
+    r = exact_ctmc.exact_loglik("SEIR", a, [100, 0, 1, 0], [o.time for o in y], [o.val[2] for o in y])
+    assert abs(r["ll"] - ll[i]) < 1e-9

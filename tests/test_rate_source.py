@@ -145,3 +145,57 @@ def test_rate_source_kernels_are_timed_when_profiling(dp, pooley):
     assert st["k_filter_small"][0] == 1 and st["k_filter_small"][1] > 0.0
     assert st["k_propagate"][0] == pf.n_obs and st["k_propagate"][1] > 0.0
     pf.close()
+
+
+def test_code_object_cache_must_be_private_and_files_are_checksummed(dp, pooley, tmp_path):
+    """The cache holds GPU code objects that dpomp_create loads: a directory other users can write to is not used, and
+    a cache file whose code object was altered (same length, so only the checksum can tell) is recompiled and replaced.
+    (Compile-only path: needs no GPU.)"""
+    import os
+    src = SOURCE.replace("theta[3]", "theta[3] * 1.0009765625")   # a text of this test's own: nothing cached in the process yet
+    rf = dp.RateSource(src, n_events=2, n_params=4, host=_host)
+    model = dp.generate_custom_model("SIS-sat-cache", rf, [100, 1], [[-1, 1], [1, -1]], prior=dp.generate_weak_prior(4))
+    old = os.environ.get("DPOMP_CACHE_DIR")
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    private = tmp_path / "private"
+    try:
+        os.environ["DPOMP_CACHE_DIR"] = str(shared)
+        dp.check_rate_source(model, pooley)
+        assert os.listdir(shared) == []                      # refused: writable by others
+        os.environ["DPOMP_CACHE_DIR"] = str(private)         # does not exist yet: created 0700
+        src2 = src.replace("1.0009765625", "1.00048828125")
+        model2 = dp.generate_custom_model("SIS-sat-cache2", dp.RateSource(src2, n_events=2, n_params=4, host=_host), [100, 1],
+                                          [[-1, 1], [1, -1]], prior=dp.generate_weak_prior(4))
+        dp.check_rate_source(model2, pooley)
+        files = [f for f in os.listdir(private) if f.endswith(".dpomprtc")]
+        assert len(files) == 1 and (os.stat(private).st_mode & 0o077) == 0
+        # flip one byte of the code object: a fresh process (nothing cached in memory) must not accept the file -- it
+        # compiles again and puts the good file back
+        path = os.path.join(private, files[0])
+        good = open(path, "rb").read()
+        bad = bytearray(good)
+        bad[len(bad) // 2] ^= 0x40
+        open(path, "wb").write(bytes(bad))
+        import subprocess
+        import sys
+        code = ("import sys; sys.path.insert(0, %r); import dpomp_amd as dp\n"
+                "src = %r\n"
+                "m = dp.generate_custom_model('SIS-sat-cache2', dp.RateSource(src, n_events=2, n_params=4), [100, 1], [[-1, 1], [1, -1]],"
+                " prior=dp.generate_weak_prior(4))\n"
+                "y = [dp.Observation(20.0, 1, 1.0, [0, 18]), dp.Observation(40.0, 1, 1.0, [0, 65])]\n"
+                "dp.check_rate_source(m, y)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), src2))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DPOMP_CACHE_DIR=str(private)))
+        assert r.returncode == 0, r.stderr[-2000:]
+        replaced = open(path, "rb").read()
+        assert replaced != bytes(bad) and replaced[:8] == good[:8]      # compiled again, written again
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DPOMP_CACHE_DIR=str(private)))
+        assert r.returncode == 0 and open(path, "rb").read() == replaced  # ... and that file is accepted as it is
+    finally:
+        if old is None:
+            os.environ.pop("DPOMP_CACHE_DIR", None)
+        else:
+            os.environ["DPOMP_CACHE_DIR"] = old

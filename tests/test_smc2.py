@@ -81,16 +81,53 @@ def test_smc2_reference_configuration_on_gpu(dp, pooley):
     prior U(0,0.01) x U(0,0.5).  Reference seed-1 value 19.98; exact 20.1676."""
     model = dp.generate_model("SIS", [100, 1])
     model.prior = dp.UniformProductPrior([0.0, 0.0], [0.01, 0.5])
-    # Measured over 20 seeds on MI355X (tools/smc2_spread.py): as written 20.07 +- 0.07, corrected 20.177 +- 0.064.
-    runs = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False) for s in range(1, 9)]
+    # Measured over 20 seeds on MI355X (tools/smc2_spread.py): as written 20.07 +- 0.07 (sd over seeds), corrected
+    # 20.177 +- 0.064.  16 seeds each: standard error of a mean ~0.017.
+    runs = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False) for s in range(1, 17)]
     bme = np.array([o.bme[0] for o in runs])
     assert runs[0].theta.shape == (2, 4000)
     assert abs(bme.mean() - REFERENCE_SEED1_BME) < 0.2, bme     # reference: bme[1] ~ 19.98 (Julia index 1), one seed
     assert bme.min() < REFERENCE_SEED1_BME + 0.07                # 19.98 lies inside our seed-to-seed scatter
-    fixed = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False, proposal_correction=True) for s in range(1, 9)]
-    assert abs(np.mean([o.bme[0] for o in fixed]) - EXACT["neg_log_evidence"]) < 0.08
+    fixed = [dp.run_ibis_analysis(model, pooley, seed=s, verbose=False, proposal_correction=True) for s in range(1, 17)]
+    bme_fixed = np.array([o.bme[0] for o in fixed])
+    # the driver as the reference wrote it carries the reference's bias: visibly BELOW the exact evidence, as its own
+    # pinned 19.98 is, and below the corrected driver, which lands on the exact value (margins ~2.5 standard errors)
+    assert bme.mean() < EXACT["neg_log_evidence"] - 0.04, (bme.mean(), EXACT["neg_log_evidence"])
+    assert bme_fixed.mean() - bme.mean() > 0.04, (bme_fixed.mean(), bme.mean())
+    assert abs(bme_fixed.mean() - EXACT["neg_log_evidence"]) < 0.06
     assert abs(np.mean([o.mu[0] for o in fixed]) - EXACT["beta_mean"]) < 0.02 * EXACT["beta_mean"]
     assert abs(np.mean([o.mu[1] for o in fixed]) - EXACT["gamma_mean"]) < 0.03 * EXACT["gamma_mean"]
+
+
+@pytest.mark.gpu
+def test_smc2_on_seir_lands_on_the_exact_evidence(dp):
+    """SMC^2 on a model other than Pooley SIS, against a known answer: the exact evidence and posterior mean of the
+    synthetic SEIR data under a uniform prior box (tests/golden/seir_evidence.json: forward algorithm over 182 002
+    states x 12^3 Gauss-Legendre nodes, quadrature error ~0.006).  With a valid PMMH kernel (independent proposals WITH
+    the q-ratio) 2048 theta-particles x 4096 state particles land on both within 3 standard errors over 8 seeds; the
+    driver as the reference wrote it (no q-ratio, src/hmm_ibis.jl:104) lands measurably elsewhere in the posterior mean.
+    Measured over 12 seeds (tools/smc2_seir_spread.py): corrected 14.419 +- 0.038 (sd over seeds; exact 14.397), recovery
+    rate 0.10082 +- 0.00032 (exact 0.10087); as written 14.352 +- 0.039 and 0.09970 +- 0.00040."""
+    exact = json.load(open(os.path.join(GOLDEN, "seir_evidence.json")))
+    assert exact["quadrature_error_estimate"] < 0.01
+    y = dp.get_observations(os.path.join(GOLDEN, "seir_synthetic.csv"))
+    model = dp.generate_model("SEIR", [100, 0, 1, 0])
+    model.prior = dp.UniformProductPrior(exact["prior"]["lower"], exact["prior"]["upper"])
+    n = 8
+    out = {}
+    for corr in (True, False):
+        runs = [dp.run_smc2_analysis(model, y, np_=2048, npf=4096, seed=s, verbose=False, proposal_correction=corr) for s in range(1, n + 1)]
+        assert all(r.n_resample >= 1 and r.status == 0 for r in runs)
+        out[corr] = (np.array([r.bme[0] for r in runs]), np.array([r.mu for r in runs]))
+    bme, mu = out[True]
+    se = lambda v, floor: max(float(np.std(v, ddof=1)), floor) / np.sqrt(n)   # (floors: the spread measured over 12 seeds)
+    assert abs(bme.mean() - exact["neg_log_evidence"]) < 3 * se(bme, 0.038) + exact["quadrature_error_estimate"], (bme, exact["neg_log_evidence"])
+    for k, floor in enumerate((1.0e-4, 6.0e-3, 3.2e-4)):
+        assert abs(mu[:, k].mean() - exact["posterior_mean"][k]) < 3 * se(mu[:, k], floor), (k, mu[:, k].mean(), exact["posterior_mean"][k])
+    mu_ref = out[False][1]
+    # without the q-ratio the sample is pulled towards the proposal mean: the recovery rate sits ~0.0012 too low (10 se)
+    assert exact["posterior_mean"][2] - mu_ref[:, 2].mean() > 6.0e-4
+    assert abs(mu[:, 2].mean() - exact["posterior_mean"][2]) < abs(mu_ref[:, 2].mean() - exact["posterior_mean"][2])
 
 
 @pytest.mark.gpu
