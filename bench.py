@@ -252,8 +252,9 @@ def main():
     ap.add_argument("--profile-every", type=int, default=10,
                     help="HIP-event brackets around the kernels of every n-th timed step (the markers cost GPU time)")
     ap.add_argument("--no-smc2", action="store_true", help="skip the SMC^2 leg (BASELINE configuration 4) after the timed region")
-    ap.add_argument("--write-smc2-reference", action="store_true",
-                    help="single GPU only: store the SMC^2 leg's evidence as the committed value runs on more GPUs must reproduce bit for bit")
+    ap.add_argument("--write-smc2-reference", default=None, metavar="FILE",
+                    help="single GPU only: store the SMC^2 leg's evidence in FILE (committed as profiles/r03/smc2_config4_single_gpu.json: "
+                         "the value runs on more GPUs must reproduce bit for bit)")
     ap.add_argument("--smc2-theta", type=int, default=512)
     ap.add_argument("--smc2-particles", type=int, default=1 << 16)
     ap.add_argument("--dry-run", action="store_true",
@@ -492,7 +493,7 @@ def main():
         if smc2 is not None:
             result["smc2_config4"] = smc2
             if args.write_smc2_reference and world == 1:
-                with open(os.path.join(ROOT, "profiles", "r03", "smc2_config4_single_gpu.json"), "w") as f:
+                with open(args.write_smc2_reference, "w") as f:
                     json.dump({"theta_particles": args.smc2_theta, "state_particles": args.smc2_particles, "seed": 3,
                                "minus_ln_evidence": smc2["minus_ln_evidence"], "posterior_mean": smc2["posterior_mean"],
                                "n_resample": smc2["n_resample"], "seconds_single_gpu": smc2["seconds"]}, f, indent=1)

@@ -61,7 +61,10 @@ const char* const kKernelNames[KID_COUNT] = {"k_init",    "k_propagate", "k_wsum
 typedef void (*PropFn)(PropArgs);
 
 constexpr int64_t kCompactionMinWaves = 4096;   // launches of at least this many waves run the compaction schedule
-constexpr int64_t kSmallFilterMaxWaves = 8192;  // calls of P <= 256 below this many waves run the whole-filter kernel
+// Calls of P <= 256 below this many waves run the whole-filter kernel; above, the filters are laid end to end over the
+// compaction kernel's workgroups (measured crossover for 200-particle filters, tools/small_filter_crossover.py: 1000
+// filters 0.815 against 0.856 ms, 1500 filters 1.153 against 1.022 ms).
+constexpr int64_t kSmallFilterMaxWaves = 4608;
 constexpr int kDefaultPropVariant = 32;  // workgroup compaction, first live-lane count after 32 events
 // Automatic schedule, per observation interval.  A launch that fills the chip (>= 4096 waves: the issue slots a
 // compaction frees are taken by other waves) runs with workgroup compaction unless, the last time this handle ran the
@@ -441,8 +444,8 @@ void pop_set_shape(dpomp_handle* h, dpomp_pop* p, int64_t B, int64_t P) {
     p->sched_offset = n_ll + n_ev + n_st;
     p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
     p->nsuper = (p->nblk + kSuperTiles - 1) / kSuperTiles;
-    // (filters of at most 32 tiles have a single group: k_offsets<true> sums their tile sums directly)
-    p->ctl_bytes = p->ctl_result_bytes + n_sm + (p->nblk > kSuperTiles ? (size_t)p->T * B * p->nsuper * kSuperStride * 8 : 0);
+    // (filters of at most 256 tiles: k_offsets<true> sums their tile sums directly, one per thread)
+    p->ctl_bytes = p->ctl_result_bytes + n_sm + (p->nblk > kBlock ? (size_t)p->T * B * p->nsuper * kSuperStride * 8 : 0);
 }
 void pop_bind_ctl(dpomp_pop* p) {
     const size_t n_ll = (size_t)p->B * 8, n_ev = 8;

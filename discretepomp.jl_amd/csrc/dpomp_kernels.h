@@ -273,31 +273,61 @@ __device__ __forceinline__ double obs_log_weight(const DevModel& m, const double
 // instructions per call, which matters inside the event loop).
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+// Reductions and the scan go through DPP row shifts and row broadcasts (one v_mov_dpp per 32-bit half and step) rather
+// than ds_bpermute shuffles, whose lane index costs four VALU instructions a step to compute.  Six steps leave the
+// inclusive scan in every lane and the total in lane 63, which goes to all lanes through an SGPR.  Integer sums and
+// max are order-free: same bits as any other reduction order.  All 64 lanes must be active at the call.
+// dpp_ctrl: 0x110 + n = row_shr:n (within rows of 16 lanes), 0x142 = row_bcast:15 (lane 15 of each row to the next
+// row), 0x143 = row_bcast:31 (lane 31 to rows 2 and 3).
+template <int CTRL, int ROWS>
+__device__ __forceinline__ unsigned long long dpp_or_zero(unsigned long long v) {  // lanes without a source read 0
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROWS, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROWS, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_or_self(int v) {  // lanes without a source read their own value
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_or_self(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_or_self<CTRL, ROWS>((int)(unsigned)u);
+    const unsigned hi = (unsigned)dpp_or_self<CTRL, ROWS>((int)(unsigned)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ unsigned long long lane63(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, int /*lane*/) {
+    v += dpp_or_zero<0x111, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v);
+    v += dpp_or_zero<0x143, 0xc>(v);
     return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) { return lane63(wave_inclusive_scan(v, 0)); }
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_or_self<0x111, 0xf>(v));
+    v = fmax(v, dpp_or_self<0x112, 0xf>(v));
+    v = fmax(v, dpp_or_self<0x114, 0xf>(v));
+    v = fmax(v, dpp_or_self<0x118, 0xf>(v));
+    v = fmax(v, dpp_or_self<0x142, 0xa>(v));
+    v = fmax(v, dpp_or_self<0x143, 0xc>(v));
+    return __longlong_as_double((long long)lane63((unsigned long long)__double_as_longlong(v)));
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long n = __shfl_up(v, off, 64);
-        if (lane >= off) v += n;
-    }
-    return v;
+    v = max(v, dpp_or_self<0x111, 0xf>(v));
+    v = max(v, dpp_or_self<0x112, 0xf>(v));
+    v = max(v, dpp_or_self<0x114, 0xf>(v));
+    v = max(v, dpp_or_self<0x118, 0xf>(v));
+    v = max(v, dpp_or_self<0x142, 0xa>(v));
+    v = max(v, dpp_or_self<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // Component s of the initial condition (pop[i,:] .= initial_condition, hmm_particle_filter.jl:42-44).
@@ -1037,8 +1067,13 @@ __global__ __launch_bounds__(kBlock, 8) void k_propagate_c(PropArgs a) {  // 8 w
     double g = -__builtin_inf();
     unsigned long long ev = 0;
     capped = false;
+    if constexpr (kFlat) {  // (re-derived here rather than kept in registers across the event loop; the lane may also
+                            // have run particles of other filters in between)
+        locate(threadIdx.x, b, p);
+        st = a.state + (int64_t)b * s_real * a.Pp;
+        th = a.theta + (int64_t)b * a.m.K;
+    }
     if (valid) {
-        if constexpr (kFlat) th = a.theta + (int64_t)b * a.m.K;  // (the lane may have run particles of other filters)
         int xv[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -1467,7 +1502,7 @@ __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
         a.blocksum[(int64_t)b * a.nblk + blk] = tile_sum;
         // second level for k_offsets<true>: 32 tiles to a sum (integer adds commute: the same bits in any order; 32
         // atomics per word do not queue up)
-        if (tile_sum && a.nblk > kSuperTiles)
+        if (tile_sum && a.nblk > kBlock)
             atomicAdd(&a.supersum[((int64_t)b * ((a.nblk + kSuperTiles - 1) / kSuperTiles) + blk / kSuperTiles) * kSuperStride], tile_sum);
         if (a.ess_frac > 0.0) {
             unsigned long long hi = s_hi[0], lo = s_lo[0];
@@ -1600,12 +1635,12 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
                 add128(hi, lo, a.blocksum2[((int64_t)b * a.nblk + i) * 2], a.blocksum2[((int64_t)b * a.nblk + i) * 2 + 1]);
             }
         } else {
-            // two levels: the sums of 32 tiles each (k_wsum) give the total and the prefix up to this tile's group, the
-            // tile sums of the group the rest -- at most 64 + 31 words per workgroup instead of all nblk tile sums
-            // (every workgroup of a 1024-tile filter used to re-read 8 KB: a third of the kernel's traffic)
+            // filters of more than 256 tiles, two levels: the sums of 32 tiles each (k_wsum) give the total and the prefix up
+            // to this tile's group, the tile sums of the group the rest -- at most 64 + 31 words per workgroup instead of
+            // all nblk tile sums (1024 tiles: 8 KB per workgroup; measured 7.9 -> 7.0 us at 2^20 particles)
             const int nsuper = (a.nblk + kSuperTiles - 1) / kSuperTiles, g = blk / kSuperTiles;
             const int t = threadIdx.x;
-            if (a.nblk <= kSuperTiles) {  // (uniform) a single group: its tile sums are all there is
+            if (a.nblk <= kBlock) {  // (uniform) one tile sum per thread: a single coalesced load, nothing to gain from two levels
                 if (t < a.nblk) {
                     tot = bs[t];
                     if (t < blk) pre = tot;

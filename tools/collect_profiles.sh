@@ -11,7 +11,7 @@ OUT=${1:-gpurun_out/prof}
 REPO=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p "$OUT"
-B="python3 bench.py --no-cpu-baseline"
+B="python3 bench.py --no-cpu-baseline --no-smc2"   # (the headline workload only: the SMC^2 leg has kernels of its own)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $B --steps 10 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $B --steps 3 --warmup 5 > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $B --steps 3 --warmup 5 > /dev/null 2> "$OUT/pmc_write.err"

@@ -18,6 +18,7 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format cs
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/hbm/pmc_write" -- $P > /dev/null 2> "$OUT/hbm/pmc_write.err"
 python3 tools/summarise_profiles.py "$OUT/hbm" "$OUT/hbm/summary"
 fi
+if [ -n "$SKIP_INTERVAL" ]; then echo "done (bench/hbm only)"; exit 0; fi
 I="python3 tools/interval_trace.py run"
 timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/interval/trace" -- $I "$OUT/interval/plan.json" > "$OUT/interval/trace.log" 2>&1
 python3 tools/interval_trace.py parse "$OUT/interval/trace" "$OUT/interval/plan.json" > "$OUT/interval/interval_trace.json"
