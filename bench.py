@@ -53,24 +53,33 @@ def valu_ceiling(family="sis"):
 
 def hbm_scale_summary():
     """The streaming kernels where the working set exceeds the 256 MiB Infinity Cache, from the latest committed
-    rocprofv3 passes (profiles/*/hbm_scale/by_launch_shape.json: 16.8 M particles per launch = 16384 workgroups):
-    bytes really moved / average duration, as a fraction of 8 TB/s."""
+    rocprofv3 passes (profiles/*/hbm_scale/<configuration>/by_launch_shape.json, one set of passes per configuration;
+    16.8 M particles per launch): bytes really moved / average duration, as a fraction of 8 TB/s, per configuration."""
     root = os.path.join(ROOT, "profiles")
+    n = 16384 * 1024  # particles per launch of both configurations
+    # bytes moved per particle: k_wsum reads the log-weight and writes the fixed-point weight; k_offsets reads that and
+    # writes the int32 boundary; k_gather (only the incremental SEIR pattern runs it) reads the boundary and moves 4 int32
+    configs = {"sis_16x2p20": {"k_wsum": 16, "k_offsets<true>": 12},
+               "seir_64x2p18": {"k_wsum": 16, "k_offsets<true>": 12},
+               "seir_64x2p18_incremental": {"k_gather": 4 + 8 * 4}}
     out = None
     for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:
-        f = os.path.join(root, d, "hbm_scale", "by_launch_shape.json")
-        if not os.path.exists(f):
-            continue
-        shapes = json.load(open(f))
-        n = 16384 * 1024  # particles of the 16384-workgroup launches
-        moved = {"k_wsum": 16 * n, "k_offsets<true>": 12 * n, "k_gather": (4 + 8 * 4) * n}  # k_gather: the SEIR shape (S = 4)
-        cur = {"source": f"profiles/{d}/hbm_scale/by_launch_shape.json", "particles_per_launch": n, "working_set": "576-832 MiB"}
-        for kname, nbytes in moved.items():
-            v = shapes.get("dpomp::" + kname, {}).get("16384 workgroups")
-            if v:
-                cur[kname.split("<")[0]] = {"avg_us": v["avg_us"], "moved_bytes": nbytes, "pmc_hbm_bytes": v.get("hbm_bytes_per_launch_corrected"),
-                                            "frac_of_8TBs": round(nbytes / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)}
-        out = cur
+        base = os.path.join(root, d, "hbm_scale")
+        cur = {"source": f"profiles/{d}/hbm_scale/<configuration>/by_launch_shape.json", "particles_per_launch": n,
+               "working_set": "576 MiB (SIS, 16 filters x 2^20) and 832 MiB (SEIR, 64 x 2^18)"}
+        for cfg, kernels in configs.items():
+            f = os.path.join(base, cfg, "by_launch_shape.json")
+            if not os.path.exists(f):
+                continue
+            shapes = json.load(open(f))
+            for kname, per_particle in kernels.items():
+                for grid, v in shapes.get("dpomp::" + kname, {}).items():
+                    nbytes = per_particle * n
+                    cur.setdefault(kname.split("<")[0], {})[cfg] = {
+                        "grid": grid, "avg_us": v["avg_us"], "moved_bytes": nbytes, "pmc_hbm_bytes": v.get("hbm_bytes_per_launch_corrected"),
+                        "frac_of_8TBs": round(nbytes / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)}
+        if len(cur) > 3:
+            out = cur
     return out
 
 

@@ -199,6 +199,7 @@ struct dpomp_handle {
     std::vector<double> wave_chain; // [T] mean over waves of the longest event chain in the wave, last call (-1 = unknown)
     int resident_wgs = 2048;        // workgroups of the compaction kernel the device holds at once (8 per CU)
     bool no_head_start = false;     // DPOMP_HEAD_START=0: experiment switch
+    int tiles_per_wg = 0;           // DPOMP_TILES_PER_WG: experiment switch (k_offsets; 0 = by grid size)
     bool no_flat = false;           // DPOMP_FLAT=0: experiment switch (small filters one per workgroup column)
     double boost_frac = kBoostChainFrac;
     int boost_wgs = 0;              // 0 = half of resident_wgs
@@ -212,7 +213,7 @@ struct dpomp_handle {
 
 struct dpomp_pop {
     int64_t B = 0, P = 0, Pp = 0;
-    int nblk = 0, nsuper = 0, S = 0, K = 0, T = 0;
+    int nblk = 0, S = 0, K = 0, T = 0;
     int32_t* state[2] = {nullptr, nullptr};
     int cur = 0;
     double* logw = nullptr;
@@ -235,7 +236,6 @@ struct dpomp_pop {
     char* h_result = nullptr;    // pinned host staging: result download and parameter upload of a call are true
     double* h_theta = nullptr;   // asynchronous copies (pageable memory makes each a blocking, staged transfer)
     unsigned long long* segmax = nullptr;  // [T][B]   (inside ctl)
-    unsigned long long* supersum = nullptr;  // [T][B][nsuper] sums of 32 tile sums each (inside ctl)
     unsigned long long* wtot = nullptr;    // [B]
     double* ll = nullptr;                  // [B]      (inside ctl)
     uint32_t* status = nullptr;            // [B]      (inside ctl)
@@ -443,9 +443,7 @@ void pop_set_shape(dpomp_handle* h, dpomp_pop* p, int64_t B, int64_t P) {
     const size_t n_sc = (size_t)p->T * kSchedStride * 8;
     p->sched_offset = n_ll + n_ev + n_st;
     p->ctl_result_bytes = n_ll + n_ev + n_st + n_sc;
-    p->nsuper = (p->nblk + kSuperTiles - 1) / kSuperTiles;
-    // (filters of at most 256 tiles: k_offsets<true> sums their tile sums directly, one per thread)
-    p->ctl_bytes = p->ctl_result_bytes + n_sm + (p->nblk > kBlock ? (size_t)p->T * B * p->nsuper * kSuperStride * 8 : 0);
+    p->ctl_bytes = p->ctl_result_bytes + n_sm;
 }
 void pop_bind_ctl(dpomp_pop* p) {
     const size_t n_ll = (size_t)p->B * 8, n_ev = 8;
@@ -453,7 +451,6 @@ void pop_bind_ctl(dpomp_pop* p) {
     p->events = reinterpret_cast<unsigned long long*>(p->ctl + n_ll);
     p->status = reinterpret_cast<uint32_t*>(p->ctl + n_ll + n_ev);
     p->segmax = reinterpret_cast<unsigned long long*>(p->ctl + p->ctl_result_bytes);
-    p->supersum = p->segmax + (size_t)p->T * p->B;
 }
 
 int check_pop_dims(dpomp_handle* h, int64_t B, int64_t P) {
@@ -793,7 +790,6 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.segmax = p->segmax + (size_t)k * B;
             w.blocksum = p->blocksum;
             w.blockprefix = p->blockprefix;
-            w.supersum = p->supersum + (size_t)k * B * p->nsuper * kSuperStride;
             w.wtot = p->wtot;
             w.ll = p->ll;
             w.status = p->status;
@@ -817,6 +813,9 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             w.P = (int32_t)p->P;
             w.nblk = p->nblk;
             w.sh = weight_shift(p->P);
+            // k_offsets: 4 tiles to a workgroup once that still leaves every CU 8 workgroups (what a workgroup needs
+            // once per launch is then paid once per 4 tiles); DPOMP_TILES_PER_WG overrides
+            w.tiles_per_wg = h->tiles_per_wg > 0 ? h->tiles_per_wg : (p->nblk >= 4 && (int64_t)B * p->nblk >= 4 * (int64_t)h->resident_wgs ? 4 : 1);
             w.obs_k = (uint32_t)k;
             w.seg_base = (uint32_t)seg_base;
             w.seed = seed;
@@ -833,8 +832,9 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             if (resample) {
                 if (!one_tile) {
                     // fused: also the tile-sum scan and the :60 update
-                    if (fused) timed_launch(h, KID_OFFSETS, k_offsets<true>, grid_tiles, block, 0, st, w);
-                    else timed_launch(h, KID_OFFSETS, k_offsets<false>, grid_tiles, block, 0, st, w);
+                    const dim3 grid_off((unsigned)((p->nblk + w.tiles_per_wg - 1) / w.tiles_per_wg), (unsigned)B);
+                    if (fused) timed_launch(h, KID_OFFSETS, k_offsets<true>, grid_off, block, 0, st, w);
+                    else timed_launch(h, KID_OFFSETS, k_offsets<false>, grid_off, block, 0, st, w);
                 }
                 if (h->rs_type != DPOMP_RS_SYSTEMATIC) {
                     GatherPosArgs gp;
@@ -1437,6 +1437,7 @@ int create_impl(const dpomp_model_desc* d, int device, const char* rate_source, 
     }
     if (const char* env = getenv("DPOMP_RPL")) h->force_rpl = atoi(env);
     if (const char* env = getenv("DPOMP_FLAT")) h->no_flat = atoi(env) == 0;
+    if (const char* env = getenv("DPOMP_TILES_PER_WG")) h->tiles_per_wg = std::min(64, std::max(0, atoi(env)));
     {
         std::vector<int32_t> oid(d->n_obs);
         for (int t = 0; t < d->n_obs; ++t) oid[t] = d->obs_id[t] > 0 ? 1 : 0;

@@ -268,6 +268,22 @@ __device__ __forceinline__ double obs_log_weight(const DevModel& m, const double
     }
 }
 
+// Where an event loop starts within the 32-byte blocks instructions are fetched in decides how well a LONE wave's
+// fetches hide behind its dependent chain (a launch that does not fill the chip: one wave per SIMD): shifting the loop
+// of the whole-filter kernel in steps of 4 bytes moved a 200-particle SIS filter between 333 and 360 us (period 32
+// bytes, smooth in between), the static kernel's between 414 and 441 us at 4096 particles; aligning every loop to 32
+// or 64 bytes (-falign-loops) gives the worst case.  The kernels that run in that regime therefore pin their loop:
+// aligned to 32 bytes and NOPS s_nop (0xBF800000) further, the compiler's own loop preheader following.  (The
+// compaction kernel, eight waves per SIMD, does not care: +-0.3 % over the same sweep.)
+#define DPOMP_LOOP_AT_(NOPS) asm volatile(".p2align 5\n.fill " #NOPS ", 4, 0xBF800000")
+#define DPOMP_LOOP_AT(NOPS) DPOMP_LOOP_AT_(NOPS)
+#ifndef DPOMP_PAD_SMALL   // (overridden by tools/loop_offset_sweep.py)
+#define DPOMP_PAD_SMALL 1
+#endif
+#ifndef DPOMP_PAD_STATIC
+#define DPOMP_PAD_STATIC 3
+#endif
+
 // ---- wave / block helpers --------------------------------------------------------------
 // Wave votes straight from the lane mask (HIP's __any/__ballot go through an integer compare in VGPRs: two VALU
 // instructions per call, which matters inside the event loop).
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
 
     if (valid) {
         Draws ahead = draw_ahead(rng, s_log, lr);
+        DPOMP_LOOP_AT(DPOMP_PAD_STATIC);
         while (gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) {}
         capped = n >= cap;
         if (!capped && stopped_on_range(time, tmax))
@@ -1220,6 +1237,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         bool capped = false;
         if (valid) {
             Draws ahead = draw_ahead(rng, s_log, lr);
+            DPOMP_LOOP_AT(DPOMP_PAD_SMALL);
             while (gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) {}
             capped = n >= cap;
             if (!capped && stopped_on_range(time, tmax))
@@ -1386,9 +1404,6 @@ struct WeightArgs {
     const unsigned long long* segmax;   // [B]
     unsigned long long* blocksum;       // [B][nblk]
     unsigned long long* blockprefix;    // [B][nblk] exclusive prefix of blocksum
-    unsigned long long* supersum;       // [B][ceil(nblk / 32)] (stride kSuperStride words: one 128-byte line each) sums of
-                                        // 32 consecutive tile sums of THIS observation (zero when k_wsum starts: the
-                                        // array lives in the control block)
     unsigned long long* wtot;           // [B]
     double* ll;                         // [B] running log-likelihood
     uint32_t* status;                   // [B]
@@ -1409,6 +1424,7 @@ struct WeightArgs {
     int64_t Pp;
     int32_t rs_type;                    // DPOMP_RS_*
     int32_t P, nblk, sh;
+    int32_t tiles_per_wg;               // k_offsets: consecutive tiles of one filter a workgroup walks (>= 1)
     uint32_t obs_k, seg_base;
     uint64_t seed;
 };
@@ -1474,9 +1490,6 @@ __device__ __forceinline__ void finish_segment(const WeightArgs& a, int b, unsig
     }
 }
 
-constexpr int kSuperTiles = 32;   // tiles per second-level sum (k_wsum -> k_offsets<true>)
-constexpr int kSuperStride = 16;  // u64 between two second-level sums: atomics on one 128-byte line serialise at the L2
-
 // k_wsum: per-tile sum of the fixed-point weights rint(exp(g - max) 2^sh).
 __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     const int b = blockIdx.y, blk = blockIdx.x;
@@ -1498,12 +1511,7 @@ __global__ __launch_bounds__(kBlock) void k_wsum(WeightArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long tile_sum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-        a.blocksum[(int64_t)b * a.nblk + blk] = tile_sum;
-        // second level for k_offsets<true>: 32 tiles to a sum (integer adds commute: the same bits in any order; 32
-        // atomics per word do not queue up)
-        if (tile_sum && a.nblk > kBlock)
-            atomicAdd(&a.supersum[((int64_t)b * ((a.nblk + kSuperTiles - 1) / kSuperTiles) + blk / kSuperTiles) * kSuperStride], tile_sum);
+        a.blocksum[(int64_t)b * a.nblk + blk] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
         if (a.ess_frac > 0.0) {
             unsigned long long hi = s_hi[0], lo = s_lo[0];
             for (int w2 = 1; w2 < kBlock / 64; ++w2) add128(hi, lo, s_hi[w2], s_lo[w2]);
@@ -1566,17 +1574,31 @@ __global__ __launch_bounds__(kBlock) void k_scan_blocks(WeightArgs a) {
     }
 }
 
+// offspring_end without branches (selects): the same operations on the same values, so the same result for every
+// input -- four calls per thread are straight-line code instead of twelve divergent regions.
+__device__ __forceinline__ int offspring_end_lane(unsigned long long c, unsigned long long W, double Wd, int P, double r) {
+    const double pos = div_in_range(u64_to_double(c), Wd) * (double)P - r;
+    double n = __builtin_ceil(pos);
+    n = n > 0.0 ? n : 0.0;
+    n = n > (double)P ? (double)P : n;
+    const int v = (int)n;
+    return c >= W ? P : v;
+}
+
 // Systematic resampling of one tile: offspring boundaries N_j of the tile's particles from their inclusive cumulative
 // weights base + c[q], and the first_parent map entries they own.  Called by every thread of the workgroup (barrier).
-__device__ __forceinline__ void systematic_boundaries(const WeightArgs& a, int b, int blk, unsigned long long tile_prefix,
-                                                      unsigned long long base, const unsigned long long (&c)[kItems],
-                                                      unsigned long long W, double r) {
+// prev_last: boundary of the particle before the tile when the caller has it (the last N of the tile it did before
+// this one), -1 to compute it from tile_prefix.  Returns (to thread 0) the last boundary of this tile.
+__device__ __forceinline__ int systematic_boundaries(const WeightArgs& a, int b, int blk, unsigned long long tile_prefix,
+                                                     unsigned long long base, const unsigned long long (&c)[kItems],
+                                                     unsigned long long W, double r, int prev_last) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    const double Wd = u64_to_double(W);
     int n[kItems];
 #pragma unroll
     for (int q = 0; q < kItems; ++q)
-        n[q] = (W == 0) ? a.P : (int)offspring_end(base + c[q], W, a.P, r);
+        n[q] = (W == 0) ? a.P : offspring_end_lane(base + c[q], W, Wd, a.P, r);
     *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
     // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
     // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
@@ -1585,12 +1607,17 @@ __device__ __forceinline__ void systematic_boundaries(const WeightArgs& a, int b
     // the neighbouring lane, by the first lane of a wave from the wave before (through LDS), and computed from the
     // tile's exclusive prefix by the first thread of the tile only -- not by every thread (a division each).
     __shared__ int s_last[kBlock / 64];
-    int lo = __shfl_up(n[kItems - 1], 1, 64);
+    int lo = __builtin_amdgcn_update_dpp(0, n[kItems - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
     if (lane == 63) s_last[wid] = n[kItems - 1];
     __syncthreads();
+    int tile_last = 0;
     if (lane == 0) {
         if (wid > 0) lo = s_last[wid - 1];
-        else lo = (W == 0) ? ((blk == 0) ? 0 : a.P) : (int)offspring_end(tile_prefix, W, a.P, r);
+        else {
+            if (prev_last >= 0) lo = prev_last;
+            else lo = (W == 0) ? ((blk == 0) ? 0 : a.P) : (int)offspring_end(tile_prefix, W, a.P, r);
+            tile_last = s_last[kBlock / 64 - 1];
+        }
     }
     int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
     const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
@@ -1603,56 +1630,42 @@ __device__ __forceinline__ void systematic_boundaries(const WeightArgs& a, int b
     // take longer than the rest of the kernel: wide ranges are filled by the whole wave, 64 entries at a time.
     for (unsigned long long todo = wave_ballot(wide); todo; todo &= todo - 1) {
         const int src = __builtin_ctzll(todo);
-        const int w0 = __shfl(t0, src, 64), w1 = __shfl(t1, src, 64), wb = __shfl(my_block, src, 64);
+        const int w0 = __builtin_amdgcn_readlane(t0, src), w1 = __builtin_amdgcn_readlane(t1, src),
+                  wb = __builtin_amdgcn_readlane(my_block, src);
         for (int t = w0 + lane; t < w1; t += 64) fp[t] = wb;
     }
+    return tile_last;
 }
 
 // k_offsets<FUSED>: inclusive fixed-point cumulative weight c_j of every particle (tile scan + tile
 // prefix) -> offspring boundary N_j.  Slots [N_{j-1}, N_j) of the resampled population copy
 // particle j: rsp_systematic's u_i = (u1 + (i-1)/P) cw[end], `while u[i] > cw[j]`
 // (hmm_pf_resample.jl:27-37) solved for i instead of walked.
+// A workgroup walks a.tiles_per_wg consecutive tiles of one filter (the next tile's weights are loaded while it works
+// on this one): what it needs once -- the prefix up to its first tile and the total W -- is then paid once for
+// several tiles, and the tile sums every workgroup of a filter reads are read by fewer of them.
 // FUSED: every workgroup sums the (<= 2048) tile sums itself -- its own exclusive prefix and the
 // total W -- so no separate scan launch is needed; workgroup 0 also adds the log mean weight to
 // the running log-likelihood (hmm_particle_filter.jl:60).  Otherwise the prefix and W come from
 // k_scan_blocks.  Also writes tile_end[blk] = N of the tile's last particle for k_gather.
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
-    const int b = blockIdx.y, blk = blockIdx.x;
+    const int b = blockIdx.y, blk0 = blockIdx.x * a.tiles_per_wg;
+    const int blk1 = min(blk0 + a.tiles_per_wg, a.nblk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __shared__ unsigned long long s_w[kBlock / 64], s_pre[kBlock / 64], s_tot[kBlock / 64], s_hi[kBlock / 64],
+    __shared__ unsigned long long s_w[2][kBlock / 64], s_pre[kBlock / 64], s_tot[kBlock / 64], s_hi[kBlock / 64],
         s_lo[kBlock / 64];
     unsigned long long tile_prefix, W;
     const bool adaptive = a.ess_frac > 0.0;
     if (FUSED) {
         const unsigned long long* bs = a.blocksum + (int64_t)b * a.nblk;
         unsigned long long pre = 0, tot = 0, hi = 0, lo = 0;
-        if (adaptive) {  // (also needs every tile's sum of squares)
-            for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
-                const unsigned long long v = bs[i];
-                tot += v;
-                if (i < blk) pre += v;
+        for (int i = threadIdx.x; i < a.nblk; i += kBlock) {
+            const unsigned long long v = bs[i];
+            tot += v;
+            if (i < blk0) pre += v;
+            if (adaptive)  // (also needs every tile's sum of squares)
                 add128(hi, lo, a.blocksum2[((int64_t)b * a.nblk + i) * 2], a.blocksum2[((int64_t)b * a.nblk + i) * 2 + 1]);
-            }
-        } else {
-            // filters of more than 256 tiles, two levels: the sums of 32 tiles each (k_wsum) give the total and the prefix up
-            // to this tile's group, the tile sums of the group the rest -- at most 64 + 31 words per workgroup instead of
-            // all nblk tile sums (1024 tiles: 8 KB per workgroup; measured 7.9 -> 7.0 us at 2^20 particles)
-            const int nsuper = (a.nblk + kSuperTiles - 1) / kSuperTiles, g = blk / kSuperTiles;
-            const int t = threadIdx.x;
-            if (a.nblk <= kBlock) {  // (uniform) one tile sum per thread: a single coalesced load, nothing to gain from two levels
-                if (t < a.nblk) {
-                    tot = bs[t];
-                    if (t < blk) pre = tot;
-                }
-            } else if (t < nsuper) {  // (nsuper <= 64: k_offsets<true> serves at most 2048 tiles)
-                const unsigned long long v = a.supersum[((int64_t)b * nsuper + t) * kSuperStride];
-                tot = v;
-                if (t < g) pre = v;
-            } else if (t >= 64 && t < 64 + kSuperTiles) {
-                const int i = g * kSuperTiles + (t - 64);
-                if (i < blk) pre = bs[i];
-            }
         }
         pre = wave_sum(pre);
         tot = wave_sum(tot);
@@ -1667,15 +1680,9 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         return;  // k_scan_blocks decided to keep this segment's population
     }
     unsigned long long w[kItems];
-    load_tile_fixed(a, b, blk, w);
-    unsigned long long c[kItems];
-    c[0] = w[0];
-#pragma unroll
-    for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + w[q];
-    const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
-    if (lane == 63) s_w[wid] = incl;
-    __syncthreads();
+    load_tile_fixed(a, b, blk0, w);
     if (FUSED) {
+        __syncthreads();
         tile_prefix = (s_pre[0] + s_pre[1]) + (s_pre[2] + s_pre[3]);
         W = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
         bool resample = true;
@@ -1684,31 +1691,43 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
             for (int w2 = 1; w2 < kBlock / 64; ++w2) add128(hi, lo, s_hi[w2], s_lo[w2]);
             resample = ess_resample(W, hi, lo, a.ess_frac, a.P);
         }
-        if (blk == 0 && threadIdx.x == 0) finish_segment(a, b, W, resample);
+        if (blk0 == 0 && threadIdx.x == 0) finish_segment(a, b, W, resample);
         if (!resample) return;  // population kept: the gather copies it identically
     } else {
-        tile_prefix = a.blockprefix[(int64_t)b * a.nblk + blk];
+        tile_prefix = a.blockprefix[(int64_t)b * a.nblk + blk0];
         W = a.wtot[b];
     }
-    unsigned long long base = tile_prefix + (incl - c[kItems - 1]);
-    for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
-
     const double r = a.rsu[b];  // rand() of hmm_pf_resample.jl:27 (drawn in k_wsum)
-    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
-    if (a.rs_type == 1) {
-        systematic_boundaries(a, b, blk, tile_prefix, base, c, W, r);
-    } else {
-        // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
-        // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
-        const double Wd = u64_to_double(W);
-        double ps[kItems];
+    int prev_last = -1;
+    for (int blk = blk0; blk < blk1; ++blk) {  // (uniform)
+        unsigned long long c[kItems];
+        c[0] = w[0];
 #pragma unroll
-        for (int q = 0; q < kItems; ++q)
-            ps[q] = (W == 0) ? (double)a.P : div_in_range(u64_to_double(base + c[q]), Wd) * (double)a.P;
-        double* dst = a.posw + (int64_t)b * a.Pp + i0;
-        *reinterpret_cast<double2*>(dst) = make_double2(ps[0], ps[1]);
-        *reinterpret_cast<double2*>(dst + 2) = make_double2(ps[2], ps[3]);
-        if (threadIdx.x == kBlock - 1) a.tile_end_pos[(int64_t)b * a.nblk + blk] = ps[kItems - 1];
+        for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + w[q];
+        if (blk + 1 < blk1) load_tile_fixed(a, b, blk + 1, w);
+        const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
+        unsigned long long* sw = s_w[(blk - blk0) & 1];  // (two buffers: the next tile writes while slow waves still read)
+        if (lane == 63) sw[wid] = incl;
+        __syncthreads();
+        unsigned long long base = tile_prefix + (incl - c[kItems - 1]);
+        for (int ww = 0; ww < wid; ++ww) base += sw[ww];
+        const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+        if (a.rs_type == 1) {
+            prev_last = systematic_boundaries(a, b, blk, tile_prefix, base, c, W, r, prev_last);
+        } else {
+            // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
+            // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
+            const double Wd = u64_to_double(W);
+            double ps[kItems];
+#pragma unroll
+            for (int q = 0; q < kItems; ++q)
+                ps[q] = (W == 0) ? (double)a.P : div_in_range(u64_to_double(base + c[q]), Wd) * (double)a.P;
+            double* dst = a.posw + (int64_t)b * a.Pp + i0;
+            *reinterpret_cast<double2*>(dst) = make_double2(ps[0], ps[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(ps[2], ps[3]);
+            if (threadIdx.x == kBlock - 1) a.tile_end_pos[(int64_t)b * a.nblk + blk] = ps[kItems - 1];
+        }
+        tile_prefix += (sw[0] + sw[1]) + (sw[2] + sw[3]);
     }
 }
 
@@ -1750,7 +1769,7 @@ __global__ __launch_bounds__(kBlock) void k_weights_tile(WeightArgs a, int resam
     if (!resample) return;  // (uniform) last observation of the data set: no resampling (:62)
     unsigned long long base = incl - c[kItems - 1];
     for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
-    systematic_boundaries(a, b, 0, 0ull, base, c, W, s_r);
+    systematic_boundaries(a, b, 0, 0ull, base, c, W, s_r, -1);
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------

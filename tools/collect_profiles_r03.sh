@@ -12,11 +12,18 @@ cd /tmp && export TMPDIR=/tmp && cd "$REPO"
 mkdir -p "$OUT/hbm" "$OUT/interval"
 [ -n "$SKIP_BENCH" ] || bash tools/collect_profiles.sh "$OUT/bench"
 if [ -z "$SKIP_HBM" ]; then
-P="python3 tools/hbm_scale_probe.py 4 sis_16x2^20 seir_64x2^18 seir_64x2^18+incremental seir_64x2^16_config4_share seir_64x2^16_config4_share+incremental"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/hbm/trace" -- $P > "$OUT/hbm/probe_under_rocprof.json" 2> "$OUT/hbm/trace.err"
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/hbm/pmc_fetch" -- $P > /dev/null 2> "$OUT/hbm/pmc_fetch.err"
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/hbm/pmc_write" -- $P > /dev/null 2> "$OUT/hbm/pmc_write.err"
-python3 tools/summarise_profiles.py "$OUT/hbm" "$OUT/hbm/summary"
+# one set of passes per configuration: two configurations can launch a kernel with the same grid (64 filters x 2^18
+# particles at 4 tiles per workgroup and 64 x 2^16 at one are both 64 x 64 workgroups of k_offsets)
+for C in "sis_16x2^20" "seir_64x2^18" "seir_64x2^18+incremental" "seir_64x2^16_config4_share" "seir_64x2^16_config4_share+incremental"; do
+D="$OUT/hbm/$(echo "$C" | tr '^+' 'p_')"
+mkdir -p "$D"
+P="python3 tools/hbm_scale_probe.py 6 $C"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- $P > "$D/probe_under_rocprof.json" 2> "$D/trace.err"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$D/pmc_fetch" -- $P > /dev/null 2> "$D/pmc_fetch.err"
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$D/pmc_write" -- $P > /dev/null 2> "$D/pmc_write.err"
+python3 tools/summarise_profiles.py "$D" "$OUT/hbm/summary/$(basename "$D")"
+cp "$D/probe_under_rocprof.json" "$OUT/hbm/summary/$(basename "$D")/"
+done
 fi
 if [ -n "$SKIP_INTERVAL" ]; then echo "done (bench/hbm only)"; exit 0; fi
 I="python3 tools/interval_trace.py run"
