@@ -673,6 +673,43 @@ def test_catalogue_models_at_chip_filling_size_all_schedules_agree(dp, orc, name
     pf.close()
 
 
+@pytest.mark.parametrize("tiles_per_wg", [2, 4, 7])
+@pytest.mark.parametrize("rs_type,ess,B,P", [(1, 0.0, 3, 6000), (2, 0.0, 2, 9000), (3, 0.0, 2, 5000), (1, 0.5, 3, 6000), (1, 0.0, 2, 1025)])
+def test_offspring_boundaries_with_several_tiles_per_workgroup(dp, orc, pooley, monkeypatch, tiles_per_wg, rs_type, ess, B, P):
+    """On chip-filling launches a workgroup of the offspring-boundary kernel walks several consecutive tiles of a filter
+    (prefix carried from tile to tile, the boundary before a tile taken from the tile before it).  Forced here at sizes
+    the oracle finishes quickly, with tile counts that are not a multiple of the group (6 and 9 tiles by 2, 4 and 7),
+    all three resamplers and the ESS-adaptive mode."""
+    monkeypatch.setenv("DPOMP_TILES_PER_WG", str(tiles_per_wg))
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), pooley, rs_type=rs_type, essc=ess, ess_adaptive=ess > 0)
+    theta = np.array([[0.003, 0.0025, 0.0035][:B], [0.1, 0.08, 0.12][:B]])
+    pop = pf.alloc_population(B, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, len(pooley), seed=5, seg_base=2)
+    for b in range(B):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=5, seg=2 + b, rs_type=rs_type, ess_frac=ess)
+        assert ll[b] == ref.ll and pf.last_status[b] == ref.status, (b, ll[b], ref.ll)
+        assert np.array_equal(pop.download(b), ref.pop)
+    pf.close()
+
+
+@pytest.mark.parametrize("unfused", [False, True])
+def test_chip_filling_launch_takes_four_tiles_per_workgroup_by_default(dp, orc, make_obs, unfused):
+    """8192 tiles or more in a launch: the default picks 4 tiles per workgroup -- 9 filters x 2^20 particles (fused tile
+    prefix) and 3 filters x (3 x 2^20 + 17) (more than 2048 tiles per filter: prefixes from the scan kernel).  Low
+    rates keep the oracle fast; parity stays bit-exact."""
+    y = make_obs([1.0, 2.0, 3.0], [[0, 1], [0, 2], [0, 1]])
+    pf = dp.ParticleFilter(dp.generate_model("SIS", [100, 1]), y)
+    B, P = (3, 3 * (1 << 20) + 17) if unfused else (9, 1 << 20)
+    theta = np.stack([np.linspace(0.0028, 0.0033, B), np.linspace(0.18, 0.22, B)])
+    pop = pf.alloc_population(B, P)
+    ll = pf.partial_log_likelihood(pop, theta, 1, 3, seed=4, seg_base=1)
+    for b in (0, B - 1):
+        ref = orc.pf_loglik(pf.desc, P, theta[:, b], seed=4, seg=1 + b, nthreads=8)
+        assert ll[b] == ref.ll
+        assert np.array_equal(pop.download(b), ref.pop)
+    pf.close()
+
+
 @pytest.mark.parametrize("rs_type,ess,P", [(2, 0.0, 5 * (1 << 20)), (3, 0.0, 4 * (1 << 20) + 4097), (1, 0.5, 3 * (1 << 20)),
                                            (2, 0.5, 3 * (1 << 20) + 5)])
 def test_many_tiles_other_resamplers_and_ess_sums(dp, orc, pooley, rs_type, ess, P):

@@ -1,5 +1,5 @@
 """Regression guard on speed: the headline workload (Pooley SIS, 2^20 particles, one full filter call) must stay within
-15 % of the committed profile (profiles/r02/bench.json, written by bench.py on the same kind of GPU), and the
+15 % of the committed profile (profiles/r03/bench.json, written by bench.py on the same kind of GPU), and the
 propagation kernel within 15 % of its committed average duration.  Collected near the end of the suite (warm GPU).
 
 Opt-in (DPOMP_TIMING_GUARD=1): a wall-clock bound on a shared GPU box -- other tenants, clock and power state -- can fail
@@ -15,7 +15,7 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("DPOMP_TIMING_GUARD") != "1", reason="wall-clock guard: opt in with DPOMP_TIMING_GUARD=1")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMITTED = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench.json")))
+COMMITTED = json.load(open(os.path.join(ROOT, "profiles", "r03", "bench.json")))
 TOLERANCE = 1.15
 
 
