@@ -268,20 +268,23 @@ __device__ __forceinline__ double obs_log_weight(const DevModel& m, const double
     }
 }
 
-// Where an event loop starts within the 32-byte blocks instructions are fetched in decides how well a LONE wave's
-// fetches hide behind its dependent chain (a launch that does not fill the chip: one wave per SIMD): shifting the loop
-// of the whole-filter kernel in steps of 4 bytes moved a 200-particle SIS filter between 333 and 360 us (period 32
-// bytes, smooth in between), the static kernel's between 414 and 441 us at 4096 particles; aligning every loop to 32
-// or 64 bytes (-falign-loops) gives the worst case.  The kernels that run in that regime therefore pin their loop:
-// aligned to 32 bytes and NOPS s_nop (0xBF800000) further, the compiler's own loop preheader following.  (The
-// compaction kernel, eight waves per SIMD, does not care: +-0.3 % over the same sweep.)
+// A LONE wave (a launch that does not fill the chip: one wave per SIMD) also waits for its own instruction fetches:
+// after the taken branch at the end of every trip of the event loop the fetch starts over at the loop's first 32-byte
+// block, and how that block and the next ones fall decides how well the fetches hide behind the dependent chain.
+// Shifting the loop of the whole-filter kernel in steps of 4 bytes moved a 200-particle SIS filter between 333 and
+// 367 us (period 32 bytes, smooth in between), the static kernel's between 413 and 441 us at 4096 particles; aligning
+// every loop to 32 or 64 bytes (-falign-loops) gives the worst case.  The kernels of that regime therefore (a) run two
+// events per trip -- the same calls, each with its own exits: one taken branch per two events (200 particles 334 ->
+// 325 us, 4096 particles 414 -> 397 us; four per trip gain nothing more) -- and (b) pin where the loop starts: aligned
+// to 32 bytes and NOPS s_nop (0xBF800000) further, the compiler's own loop preheader following.  (The compaction
+// kernel, eight waves per SIMD, does not care: +-0.3 % over the same sweep.)
 #define DPOMP_LOOP_AT_(NOPS) asm volatile(".p2align 5\n.fill " #NOPS ", 4, 0xBF800000")
 #define DPOMP_LOOP_AT(NOPS) DPOMP_LOOP_AT_(NOPS)
 #ifndef DPOMP_PAD_SMALL   // (overridden by tools/loop_offset_sweep.py)
-#define DPOMP_PAD_SMALL 1
+#define DPOMP_PAD_SMALL 4
 #endif
 #ifndef DPOMP_PAD_STATIC
-#define DPOMP_PAD_STATIC 3
+#define DPOMP_PAD_STATIC 0
 #endif
 
 // ---- wave / block helpers --------------------------------------------------------------
@@ -600,7 +603,10 @@ __global__ __launch_bounds__(kBlock) void k_propagate(PropArgs a) {
     if (valid) {
         Draws ahead = draw_ahead(rng, s_log, lr);
         DPOMP_LOOP_AT(DPOMP_PAD_STATIC);
-        while (gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) {}
+        for (;;) {  // (two events per trip: see DPOMP_LOOP_AT)
+            if (!gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) break;
+            if (!gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) break;
+        }
         capped = n >= cap;
         if (!capped && stopped_on_range(time, tmax))
             capped = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);
@@ -1238,7 +1244,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_small(SmallArgs a) {
         if (valid) {
             Draws ahead = draw_ahead(rng, s_log, lr);
             DPOMP_LOOP_AT(DPOMP_PAD_SMALL);
-            while (gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) {}
+            for (;;) {  // (two events per trip: see DPOMP_LOOP_AT)
+                if (!gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) break;
+                if (!gillespie_event<R, true, true>(a.m, rows, thr, x, time, tmax, rng, ahead, e_real, s_log, lr, &n, cap)) break;
+            }
             capped = n >= cap;
             if (!capped && stopped_on_range(time, tmax))
                 capped = finish_slow<R>(a.m, rows, thr, x, time, tmax, rng, ahead, cap, e_real, s_log, lr);

@@ -150,7 +150,15 @@ def main():
         if loop is None:
             out["kernels"][label] = {"error": "event loop not found", **meta}
             continue
-        out["kernels"][label] = {**meta, "loop_instructions": len(loop), **classify(loop)}
+        c = classify(loop)
+        trips = max(1, c["valu_mix"].get("v_rcp_f64", 1))  # events per trip of the loop (the lone-wave kernels run two)
+        if trips > 1:
+            for key in ("valu", "valu_light", "valu_trans", "salu", "lds", "vmem", "waitcnt_nop", "branch"):
+                c[key] = c[key] / trips
+            c["issue_slots_per_event"] = round(c["issue_slots_per_event"] / trips, 2)
+            c["cycles_per_wave_event"] = round(c["cycles_per_wave_event"] / trips, 1)
+            c["ceiling_events_per_s"] *= trips
+        out["kernels"][label] = {**meta, "loop_instructions": len(loop), "events_per_trip": trips, **c}
     text = json.dumps(out, indent=1)
     if args.out:
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
