@@ -146,7 +146,7 @@ def pmc_traffic(kernel):
     WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if no profile is present."""
     best = None
     root = os.path.join(ROOT, "profiles")
-    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:  # (the latest round's bench passes win)
+    for d in sorted(os.listdir(root)) if os.path.isdir(root) else []:  # (the latest committed bench passes win)
         for sub in ("", "bench"):
             f = os.path.join(root, d, sub, "pmc_hbm_traffic.json")
             if os.path.exists(f):

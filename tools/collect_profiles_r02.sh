@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence of round 2 (run on the GPU box from the repo root):  bash tools/collect_profiles_r02.sh gpurun_out/prof2
+# rocprofv3 evidence under profiles/r02 (run on the GPU box from the repo root):  bash tools/collect_profiles_r02.sh gpurun_out/prof2
 #  bench passes      as tools/collect_profiles.sh (kernel trace + stats, FETCH_SIZE, WRITE_SIZE, SQ counters)
 #  hbm-scale passes  tools/hbm_scale_probe.py at working sets beyond the 256 MiB Infinity Cache: kernel trace + stats,
 #                    FETCH_SIZE and WRITE_SIZE in runs of their own

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence of round 3 (run on the GPU box from the repo root):  bash tools/collect_profiles_r03.sh gpurun_out/prof3
+# rocprofv3 evidence under profiles/r03 (run on the GPU box from the repo root):  bash tools/collect_profiles_r03.sh gpurun_out/prof3
 #  bench passes      as tools/collect_profiles.sh (kernel trace + stats, FETCH_SIZE, WRITE_SIZE, SQ counters)
 #  hbm-scale passes  tools/hbm_scale_probe.py at working sets beyond the 256 MiB Infinity Cache
 #  interval passes   tools/interval_trace.py: kernel trace and SQ counters per observation interval of every
