@@ -822,7 +822,10 @@ int run_partial(dpomp_handle* h, dpomp_pop* p, const double* theta, int ymin, in
             const bool resample = obs_i < T;  // :62  (the ESS criterion is commented out in the reference, :63-68)
             // a filter of at most one tile: weights, their sum, the :60 update and the offspring boundaries in ONE launch
             const bool one_tile = p->nblk == 1 && !adaptive && h->rs_type == DPOMP_RS_SYSTEMATIC;
-            if (one_tile) timed_launch(h, KID_WEIGHTS_TILE, k_weights_tile, dim3((unsigned)B), block, 0, st, w, resample ? 1 : 0);
+            if (one_tile) {  // (1 / 2 / 4 particles per thread: every thread of the workgroup has one to weigh from 256 particles down)
+                auto kernel = p->P <= kBlock ? k_weights_tile<1> : p->P <= 2 * kBlock ? k_weights_tile<2> : k_weights_tile<4>;
+                timed_launch(h, KID_WEIGHTS_TILE, kernel, dim3((unsigned)B), block, 0, st, w, resample ? 1 : 0);
+            }
             else timed_launch(h, KID_WSUM, k_wsum, grid_tiles, block, 0, st, w);
             const bool fused = resample && p->nblk <= kFusedScanMaxTiles;
             if (!fused && !one_tile) {

@@ -1598,17 +1598,22 @@ __device__ __forceinline__ int offspring_end_lane(unsigned long long c, unsigned
 // weights base + c[q], and the first_parent map entries they own.  Called by every thread of the workgroup (barrier).
 // prev_last: boundary of the particle before the tile when the caller has it (the last N of the tile it did before
 // this one), -1 to compute it from tile_prefix.  Returns (to thread 0) the last boundary of this tile.
+template <int ITEMS>  // particles per thread: kItems in the tiled kernels; 1 or 2 for filters of at most 256 / 512 particles
 __device__ __forceinline__ int systematic_boundaries(const WeightArgs& a, int b, int blk, unsigned long long tile_prefix,
-                                                     unsigned long long base, const unsigned long long (&c)[kItems],
+                                                     unsigned long long base, const unsigned long long (&c)[ITEMS],
                                                      unsigned long long W, double r, int prev_last) {
+    static_assert(ITEMS == 1 || ITEMS == 2 || ITEMS == 4, "the particles of a thread share a block of 256");
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
+    const int64_t i0 = (int64_t)blk * (kBlock * ITEMS) + threadIdx.x * ITEMS;
     const double Wd = u64_to_double(W);
-    int n[kItems];
+    int n[ITEMS];
 #pragma unroll
-    for (int q = 0; q < kItems; ++q)
+    for (int q = 0; q < ITEMS; ++q)
         n[q] = (W == 0) ? a.P : offspring_end_lane(base + c[q], W, Wd, a.P, r);
-    *reinterpret_cast<int4*>(a.offs + (int64_t)b * a.Pp + i0) = make_int4(n[0], n[1], n[2], n[3]);
+    int32_t* const offs = a.offs + (int64_t)b * a.Pp + i0;
+    if constexpr (ITEMS == 4) *reinterpret_cast<int4*>(offs) = make_int4(n[0], n[1], n[2], n[3]);
+    else if constexpr (ITEMS == 2) *reinterpret_cast<int2*>(offs) = make_int2(n[0], n[1]);
+    else offs[0] = n[0];
     // Inverse map for the gather: every 256-slot OUTPUT block t learns which parent block (of 256) its first slot
     // (t * 256) copies from.  Particle j owns the slots [N_{j-1}, N_j), so the particle whose range contains
     // t * 256 writes first_parent[t] = its block; exactly one writer per output block, no cross-workgroup
@@ -1616,8 +1621,8 @@ __device__ __forceinline__ int systematic_boundaries(const WeightArgs& a, int b,
     // the neighbouring lane, by the first lane of a wave from the wave before (through LDS), and computed from the
     // tile's exclusive prefix by the first thread of the tile only -- not by every thread (a division each).
     __shared__ int s_last[kBlock / 64];
-    int lo = __builtin_amdgcn_update_dpp(0, n[kItems - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-    if (lane == 63) s_last[wid] = n[kItems - 1];
+    int lo = __builtin_amdgcn_update_dpp(0, n[ITEMS - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    if (lane == 63) s_last[wid] = n[ITEMS - 1];
     __syncthreads();
     int tile_last = 0;
     if (lane == 0) {
@@ -1629,9 +1634,9 @@ __device__ __forceinline__ int systematic_boundaries(const WeightArgs& a, int b,
         }
     }
     int32_t* fp = a.tile_end + (int64_t)b * (a.Pp / kParentBlock);
-    const int my_block = (int)(i0 / kParentBlock);  // (the 4 particles of a thread share a 256-block)
+    const int my_block = (int)(i0 / kParentBlock);  // (the particles of a thread share a 256-block)
     // the thread's particles own the slots [lo, n[3]): entries t with t * 256 in that range
-    const int t0 = (lo + kParentBlock - 1) / kParentBlock, t1 = (n[kItems - 1] + kParentBlock - 1) / kParentBlock;
+    const int t0 = (lo + kParentBlock - 1) / kParentBlock, t1 = (n[ITEMS - 1] + kParentBlock - 1) / kParentBlock;
     const bool wide = t1 - t0 > 2;
     if (!wide)
         for (int t = t0; t < t1; ++t) fp[t] = my_block;
@@ -1722,7 +1727,7 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
         for (int ww = 0; ww < wid; ++ww) base += sw[ww];
         const int64_t i0 = (int64_t)blk * kTile + threadIdx.x * kItems;
         if (a.rs_type == 1) {
-            prev_last = systematic_boundaries(a, b, blk, tile_prefix, base, c, W, r, prev_last);
+            prev_last = systematic_boundaries<kItems>(a, b, blk, tile_prefix, base, c, W, r, prev_last);
         } else {
             // stratified / multinomial: scaled cumulative weights pos_j = c_j / W * P; slot i later takes the
             // first j with pos_j > t_i.  W == 0: pos = P for every j, so every slot copies particle 0.
@@ -1746,25 +1751,36 @@ __global__ __launch_bounds__(kBlock) void k_offsets(WeightArgs a) {
 // (hmm_pf_resample.jl:24-42) come from one workgroup per filter -- one launch per observation instead of two, and the
 // weights never go through memory.  Same arithmetic, operation for operation, as the two-kernel path (integer sums are
 // order-free).  Systematic resampling, non-adaptive mode.
+template <int ITEMS>  // particles per thread: 1 / 2 / 4 for filters of at most 256 / 512 / 1024 particles (all 256 threads busy)
 __global__ __launch_bounds__(kBlock) void k_weights_tile(WeightArgs a, int resample) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __shared__ unsigned long long s_w[kBlock / 64];
     __shared__ double s_r;
     const double m = ordered_value(a.segmax[b]);
-    const int64_t i0 = threadIdx.x * kItems;
-    unsigned long long c[kItems] = {0ull, 0ull, 0ull, 0ull};
+    const int64_t i0 = threadIdx.x * ITEMS;
+    unsigned long long c[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) c[q] = 0ull;
     if (i0 < a.P) {  // (threads past the filter hold zero weights: no load)
         const double* src = a.logw + (int64_t)b * a.Pp + i0;
-        const double2 g01 = *reinterpret_cast<const double2*>(src);
-        const double2 g23 = *reinterpret_cast<const double2*>(src + 2);
-        const double g[kItems] = {g01.x, g01.y, g23.x, g23.y};
+        double g[ITEMS];
+        if constexpr (ITEMS == 4) {
+            const double2 g01 = *reinterpret_cast<const double2*>(src);
+            const double2 g23 = *reinterpret_cast<const double2*>(src + 2);
+            g[0] = g01.x, g[1] = g01.y, g[2] = g23.x, g[3] = g23.y;
+        } else if constexpr (ITEMS == 2) {
+            const double2 g01 = *reinterpret_cast<const double2*>(src);
+            g[0] = g01.x, g[1] = g01.y;
+        } else {
+            g[0] = src[0];
+        }
 #pragma unroll
-        for (int q = 0; q < kItems; ++q) c[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
+        for (int q = 0; q < ITEMS; ++q) c[q] = (i0 + q < a.P) ? fixed_weight(g[q], m, a.sh) : 0ull;
     }
 #pragma unroll
-    for (int q = 1; q < kItems; ++q) c[q] = c[q - 1] + c[q];
-    const unsigned long long incl = wave_inclusive_scan(c[kItems - 1], lane);
+    for (int q = 1; q < ITEMS; ++q) c[q] = c[q - 1] + c[q];
+    const unsigned long long incl = wave_inclusive_scan(c[ITEMS - 1], lane);
     if (lane == 63) s_w[wid] = incl;
     if (threadIdx.x == 0) {  // rand() of hmm_pf_resample.jl:27
         Stream rs = stream_init(a.seed, a.seg_base + (uint32_t)b, 0u, a.obs_k, DOMAIN_RESAMPLE);
@@ -1776,9 +1792,9 @@ __global__ __launch_bounds__(kBlock) void k_weights_tile(WeightArgs a, int resam
     const unsigned long long W = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
     if (threadIdx.x == 0) finish_segment(a, b, W, true);
     if (!resample) return;  // (uniform) last observation of the data set: no resampling (:62)
-    unsigned long long base = incl - c[kItems - 1];
+    unsigned long long base = incl - c[ITEMS - 1];
     for (int ww = 0; ww < wid; ++ww) base += s_w[ww];
-    systematic_boundaries(a, b, 0, 0ull, base, c, W, s_r, -1);
+    systematic_boundaries<ITEMS>(a, b, 0, 0ull, base, c, W, s_r, -1);
 }
 
 // ---- k_gather: m_pop[i,:] .= old_p[j_i,:]   (hmm_pf_resample.jl:38) -----------------------------
@@ -1823,7 +1839,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherArgs a) {
         int4* ldst = reinterpret_cast<int4*>(s_n);
         for (int t = threadIdx.x; t < ntiles * (kTile / 4); t += kBlock) ldst[t] = gsrc[t];
         __syncthreads();
-        const int M = ntiles * kTile;
+        const int M = min(ntiles * kTile, a.P - tlo * kTile);  // (boundaries past the last particle need not exist)
         int lo[kItems];
 #pragma unroll
         for (int q = 0; q < kItems; ++q) lo[q] = 0;

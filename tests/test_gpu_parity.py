@@ -43,7 +43,7 @@ def test_device_numerics_match_oracle_bitwise(sis, orc):
 
 # 0 = default: whole-filter kernel for P <= 256; 33 = compaction kernel with small filters laid end to end over the workgroups
 @pytest.mark.parametrize("rpl", [0, 1, 2, 4, 16, 32, 33])
-@pytest.mark.parametrize("P", [1, 63, 64, 65, 200, 256, 257, 1000, 1024, 1025, 4097])
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 200, 256, 257, 511, 512, 513, 1000, 1024, 1025, 4097])
 def test_sis_full_filter_matches_oracle(sis, orc, P, rpl):
     """Every propagation-kernel variant (one particle per lane; LDS queue with 2 / 4 per lane; workgroup compaction,
     also with filters laid end to end)."""
