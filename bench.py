@@ -368,9 +368,23 @@ def main():
 
     # BASELINE configuration 4 after the timed region: the one path with real inter-GPU traffic (theta-level migration)
     smc2 = None
+    leg = None
     if not args.no_smc2:
-        leg = smc2_config4(dp, lambda model, y: dp.ParticleFilter(model, y, device=local_rank), args.smc2_theta, args.smc2_particles,
-                           distributed=dist is not None)
+        # (a failure of this leg must not take the timed result with it: it is reported in the line instead)
+        try:
+            leg = smc2_config4(dp, lambda model, y: dp.ParticleFilter(model, y, device=local_rank), args.smc2_theta,
+                               args.smc2_particles, distributed=dist is not None)
+            leg_error = None
+        except Exception as e:  # noqa: BLE001
+            leg_error = f"{type(e).__name__}: {e}"
+        if dist is not None:  # every rank reports the leg or none does
+            ok = torch.tensor([0 if leg_error else 1], dtype=torch.int64, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok[0]) == 0:
+                leg, leg_error = None, leg_error or "the leg failed on another rank"
+        if leg is None:
+            smc2 = {"error": leg_error}
+    if leg is not None:
         rows = [leg["rows_received"]]
         if dist is not None:
             r_all = torch.zeros(world, dtype=torch.int64, device="cuda")
